@@ -1,0 +1,193 @@
+/*
+ * trainner_hip.h -- C ABI of libtrainner_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the SRModel.optimize_parameters hot path of traiNNer-redux
+ * (reference: traiNNer/models/sr_model.py:452-828).  The reference is 100 % Python and has
+ * no FFI of its own: its plugin surface is ARCH_REGISTRY / LOSS_REGISTRY
+ * factories returning torch.nn.Module.  The entry points below are therefore what a ctypes
+ * binding inside those factories binds (INTEGRATION.md shows the stub); each one cites the
+ * reference arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); nothing allocates,
+ *     synchronises or touches the host: every entry point is hipGraph-capturable;
+ *   - activations are NHWC ("channels last", the layout the reference selects with
+ *     use_channels_last, sr_model.py:50-54); a tr_view addresses a channel slice
+ *     [coff, coff+c) of an NHWC buffer whose pixel record holds `cstride` channels, which is
+ *     how dense-block concatenation (torch.cat in ResidualDenseBlock, reference twin
+ *     traiNNer/archs/scunet_aaf6aa_arch.py:328-334) becomes free;
+ *   - return value: 0 on success, a hipError_t (>0) from the launch, or a negative TR_E* code
+ *     for a rejected argument.  tr_last_error() returns a message for the calling thread.
+ *     Messages never contain the words "allocate" or "CUDA": the reference's training loop
+ *     treats such RuntimeErrors as out-of-memory and retries (train.py:757-849).
+ */
+#ifndef TRAINNER_HIP_H
+#define TRAINNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TR_ABI_VERSION 1
+
+enum { TR_F32 = 0, TR_BF16 = 1 };
+enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
+enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2 };
+enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
+enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1 };
+enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
+
+/* channel-slice view of an NHWC buffer (ptr == NULL means "absent") */
+typedef struct tr_view {
+    void*   ptr;      /* base of the NHWC buffer                                  */
+    int32_t dtype;    /* TR_F32 | TR_BF16                                          */
+    int32_t cstride;  /* channels per pixel record of the underlying buffer        */
+    int32_t coff;     /* first channel of the view                                 */
+    int32_t c;        /* channels in the view                                      */
+} tr_view;
+
+int         tr_abi_version(void);
+const char* tr_last_error(void);
+/* number of bytes of packed weights for a (cin, cout) 3x3 conv in `compute` dtype */
+size_t      tr_conv3x3_packed_bytes(int cin, int cout, int compute);
+
+/* ---- 3x3 stride-1 pad-1 convolution as implicit GEMM on MFMA ------------------------------
+ * Replaces torch.nn.Conv2d(k=3,s=1,p=1) + the pointwise ops the reference applies around it:
+ *   RDB conv1-4 + LeakyReLU(0.2)                 scunet_aaf6aa_arch.py:321-333
+ *   RDB conv5 `x5*0.2 + x`, RRDB `out*0.2 + x`   scunet_aaf6aa_arch.py:334-336,355-360
+ *   nn.Upsample(nearest x2) -> conv -> LeakyReLU scunet_aaf6aa_arch.py:371-377
+ *   VGG19 conv + ReLU, replicate pad on conv1_1  losses/perceptual_fp16_loss.py:262-274,321-329
+ * and, with flipped/transposed packed weights, the input-gradient of the same convs
+ * (what autograd's conv backward computes at sr_model.py:681).
+ *
+ *   v  = conv(in) + bias ; v = act(v)
+ *   v  = v*scale1 + res1 ; v = v*scale2 + res2          (each only if resN.ptr != NULL)
+ *   v *= (mask > 0 ? 1 : mask_slope)                      (only if mask.ptr  != NULL)
+ *   out = (out.dtype) v ; out2 = (out2.dtype)(v*out2_scale)   (out2 optional)
+ *
+ * compute = TR_BF16: in.dtype must be TR_BF16, operands bf16, fp32 accumulate
+ *           (v_mfma_f32_32x32x16_bf16); compute = TR_F32: in.dtype TR_F32, exact fp32
+ *           (v_mfma_f32_32x32x2_f32).  Epilogue arithmetic is always fp32.
+ */
+typedef struct tr_conv3x3_desc {
+    int32_t n, h, w;          /* OUTPUT batch / height / width                                */
+    int32_t cin, cout;
+    int32_t compute;          /* TR_F32 | TR_BF16                                             */
+    int32_t in_mode;          /* TR_IN_DIRECT (input n x h x w) | TR_IN_NEAREST2X (n x h/2 x w/2) */
+    int32_t pad_mode;         /* TR_PAD_ZEROS | TR_PAD_REPLICATE                              */
+    int32_t act;              /* TR_ACT_*                                                     */
+    float   slope;            /* LeakyReLU negative slope                                     */
+    float   scale1, scale2;
+    float   mask_slope;
+    float   out2_scale;
+    tr_view in, out, out2, res1, res2, mask;
+    const void*  wpacked;     /* from tr_pack_conv3x3 (layout documented in DESIGN.md)        */
+    const float* bias;        /* cout floats or NULL                                          */
+} tr_conv3x3_desc;
+
+int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
+
+/* ---- weight packing -------------------------------------------------------------------------
+ * Master weights stay fp32 OIHW (the state-dict layout the reference saves and spandrel loads,
+ * base_model.py:395-482).  A segment copies the sub-block src[o_off:o_off+o_cnt, i_off:i_off+i_cnt]
+ * of an OIHW tensor into a packed conv operand as rows [dst_o_off, +o_cnt) / columns
+ * [dst_i_off, +i_cnt); `transpose` != 0 swaps the roles of O and I and flips the taps
+ * (the weights of the input-gradient conv).  Segments live in device memory so one launch
+ * re-packs a whole network after an optimizer step.
+ */
+typedef struct tr_pack_seg {
+    const float* src;         /* OIHW fp32, dims src_o x src_i x 3 x 3                        */
+    void*        dst;         /* packed operand of a conv with dims (dst_cin, dst_cout)       */
+    int32_t src_o, src_i;
+    int32_t o_off, o_cnt, i_off, i_cnt;
+    int32_t dst_cin, dst_cout;
+    int32_t dst_o_off, dst_i_off;   /* in the packed conv's (cout, cin) index space           */
+    int32_t transpose;
+    int32_t compute;          /* TR_F32 | TR_BF16                                             */
+    int64_t first;            /* exclusive prefix sum of o_cnt*i_cnt*9 over segments (host-filled) */
+} tr_pack_seg;
+
+int tr_pack_conv3x3(void* stream, const tr_pack_seg* segs_dev, int nsegs, int64_t total_elems);
+
+/* ---- weight gradient of the 3x3 conv --------------------------------------------------------
+ * dW[co][ci][ky][kx] (+)= sum_{n,y,x} gy[n,y,x,co] * in[n,y+ky-1,x+kx-1,ci]   (OIHW fp32)
+ * db[co] (+)= sum gy[...,co]            -- what autograd accumulates into .grad at sr_model.py:681.
+ * `partials` is a caller-provided fp32 workspace of tr_wgrad3x3_workspace_bytes(); the result is
+ * bitwise reproducible (no float atomics).  accumulate != 0 adds into dw/db.
+ */
+typedef struct tr_wgrad3x3_desc {
+    int32_t n, h, w;          /* spatial size of gy (= conv output size)                      */
+    int32_t cin, cout;
+    int32_t compute;
+    int32_t in_mode, pad_mode;
+    int32_t accumulate;
+    tr_view in, gy;
+    float*  dw;               /* cout x cin x 3 x 3                                           */
+    float*  db;               /* cout or NULL                                                 */
+    float*  partials;
+    size_t  partials_bytes;
+} tr_wgrad3x3_desc;
+
+size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout);
+int    tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d);
+
+/* ---- layout / pointwise ----------------------------------------------------------------------
+ * NCHW fp32 image batch (the DataFeed contract, utils/types.py:10-17) -> NHWC view, optionally
+ * (x - mean[c]) / std[c] (perceptual_fp16_loss.py:322) ; channels of the view beyond c_src are zeroed.
+ */
+int tr_nchw_to_nhwc(void* stream, const float* src, int n, int c_src, int h, int w,
+                    tr_view dst, const float* mean3, const float* std3);
+/* NHWC view -> NCHW fp32 (network output handed back to the trainer, sr_model.py:478-479) */
+int tr_nhwc_to_nchw(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w);
+/* gradient of tr_nchw_to_nhwc wrt src: dst_nchw[c] = g[c] / std[c] */
+int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w,
+                           const float* inv_std3, int accumulate);
+/* out = (out.dtype)(in * scale) for NHWC views of equal shape */
+int tr_scale_copy(void* stream, tr_view in, tr_view out, int64_t npix, float scale);
+/* 2x2/2 max pooling (torchvision VGG19 features 'M', perceptual_fp16_loss.py:12-50) with fused
+ * preceding ReLU: out = maxpool(relu?(in)); backward routes to the first maximal element like ATen. */
+int tr_maxpool2x2(void* stream, tr_view in, tr_view out, int n, int h_in, int w_in, int relu_first);
+int tr_maxpool2x2_bwd(void* stream, tr_view in, tr_view gout, tr_view gin, int n, int h_in, int w_in,
+                      int relu_first);
+
+/* ---- pixel-loss heads -------------------------------------------------------------------------
+ * l1 / mse / charbonnier with reduction 'mean' (basic_loss.py:16-28, loss_util.py:8-59):
+ *   loss_out[0] (+)= weight * mean(elem(pred - target)) ;  grad = weight * d elem / d pred / numel
+ * Works on flat fp32 or bf16 arrays (NCHW image batches and NHWC feature maps alike).  One pass
+ * reads pred and target once and writes grad once; the scalar is reduced without float atomics
+ * (fixed-order two-level sum) so it is bitwise reproducible.  grad may be NULL (forward only).
+ */
+int tr_pixel_loss(void* stream, int kind, const void* pred, const void* target, int dtype,
+                  int64_t numel, float weight, float eps, float* loss_out, int accumulate_loss,
+                  void* grad, int grad_dtype, int accumulate_grad, float* partials /* >= 1024 floats */);
+
+/* ---- optimizer sweep --------------------------------------------------------------------------
+ * torch.optim.AdamW (optimizers/__init__.py:30-47, templates: lr 2e-4, betas (0.9, 0.99), wd 0)
+ * + ema-pytorch lerp (sr_model.py:226-235, :826-828) + global-norm clipping (sr_model.py:696-711)
+ * over ONE flat fp32 parameter arena (params / grads / exp_avg / exp_avg_sq / ema all numel long).
+ *   tr_sumsq: partial sums of squares of grads -> norm_out[0] = ||g||_2   (grad_norm_g)
+ *   tr_adamw_ema: p,m,v,ema updated in one pass; grad scaled by min(1, clip/(norm+1e-6)) when
+ *   clip > 0 (clip_grad_norm_ semantics), using the device-resident norm (no host sync);
+ *   grads are zeroed in the same pass when zero_grad != 0 (optimizer.zero_grad(), sr_model.py:719).
+ */
+int tr_sumsq(void* stream, const float* x, int64_t numel, float* norm_out, float* partials);
+typedef struct tr_adamw_desc {
+    float*  p; float* g; float* m; float* v; float* ema;   /* ema may be NULL */
+    int64_t numel;
+    float   lr, beta1, beta2, eps, weight_decay;
+    float   bias_corr1, bias_corr2;     /* 1 - beta^t, host computed */
+    float   ema_decay;                  /* decay for this step (1.0 = keep, 0.0 = copy) */
+    float   clip;                       /* <= 0: no clipping */
+    const float* grad_norm;             /* device scalar from tr_sumsq (needed if clip > 0) */
+    int32_t zero_grad;
+} tr_adamw_desc;
+int tr_adamw_ema(void* stream, const tr_adamw_desc* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAINNER_HIP_H */

@@ -1,0 +1,56 @@
+"""Precision policies for the oracle (test infrastructure, see oracle/__init__.py).
+
+`fp32`      : the reference CPU path as its own test runs it (use_amp False,
+              /root/reference/tests/test_models/test_sr_model.py:31-32).
+`bf16_ops`  : same op order, but every convolution rounds its two MFMA operands (activation and
+              weight; in backward also the incoming gradient) to bfloat16 and accumulates in fp32,
+              which is the arithmetic contract of the HIP bf16 path (DESIGN.md section "numerics").
+              Everything outside the contraction (bias, LeakyReLU, residual adds, loss, AdamW)
+              stays fp32.  This is *more* precise than the reference's own AMP path
+              (autocast also rounds conv outputs and residual adds to bf16,
+              /root/reference/traiNNer/models/sr_model.py:474-478).
+"""
+from __future__ import annotations
+
+import torch
+from torch.nn import functional as F
+
+
+def _r(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _ConvBf16Ops(torch.autograd.Function):
+    """conv2d whose contraction operands are bf16-rounded in fwd, dgrad and wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        xr, wr = _r(x), _r(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.stride, ctx.padding, ctx.has_bias = stride, padding, b is not None
+        return F.conv2d(xr, wr, b, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = _r(gy)
+        gx = torch.nn.grad.conv2d_input(xr.shape, wr, gr, stride=ctx.stride, padding=ctx.padding)
+        gw = torch.nn.grad.conv2d_weight(xr, wr.shape, gr, stride=ctx.stride, padding=ctx.padding)
+        gb = gr.sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        return gx, gw, gb, None, None
+
+
+class Policy:
+    def __init__(self, name: str) -> None:
+        if name not in ("fp32", "bf16_ops"):
+            raise ValueError(name)
+        self.name = name
+
+    def conv2d(self, x, w, b=None, stride=1, padding=1):
+        if self.name == "fp32":
+            return F.conv2d(x, w, b, stride=stride, padding=padding)
+        return _ConvBf16Ops.apply(x, w, b, stride, padding)
+
+
+FP32 = Policy("fp32")
+BF16_OPS = Policy("bf16_ops")

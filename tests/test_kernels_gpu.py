@@ -1,0 +1,323 @@
+"""Parity of every C-ABI kernel (called through the ctypes binding, i.e. through the C ABI) against
+plain PyTorch fp32 CPU references of the same op.  Tolerances:
+  * fp32 compute (v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain): rel-L2 <= 2e-6
+  * bf16 compute on bf16-representable operands, fp32 output: rel-L2 <= 2e-6 (only the summation
+    order differs); bf16 output adds one RNE rounding: max elementwise rel <= 2^-8, rel-L2 <= 1e-3
+    (the tolerance BASELINE.json north_star states for bf16 activations).
+"""
+import math
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def nhwc(t):  # NCHW -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def pack(ops, L, w, cin, cout, compute, dev, transpose=False):
+    buf = torch.zeros(ops.packed_bytes(cin, cout, compute), dtype=torch.uint8, device=dev)
+    plan = ops.PackPlan(dev)
+    plan.add(w, buf, cin, cout, compute, transpose=transpose)
+    plan.run()
+    return buf
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 64, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 3),
+                                   (1, 9, 31, 32, 128)])
+def test_conv3x3_forward(cuda, compute_name, shape):
+    import trainner_redux_amd  # noqa: F401
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cin, cout = shape
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    g = torch.Generator().manual_seed(1234 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    if compute == L.BF16:
+        x, wt = bf(x), bf(wt)
+    ref = F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.2)
+    xd = nhwc(x).to(cuda, dt)
+    wp = pack(ops, L, wt.to(cuda), cin, cout, compute, cuda)
+    out = torch.empty(n, h, w, cout, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=b.to(cuda),
+                act=L.ACT_LRELU, slope=0.2)
+    got = nchw(out.cpu())
+    assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
+
+
+def test_conv3x3_bf16_output_rounding(cuda):
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cin, cout = 1, 24, 48, 64, 64
+    g = torch.Generator().manual_seed(7)
+    x = bf(torch.randn(n, cin, h, w, generator=g))
+    wt = bf(torch.randn(cout, cin, 3, 3, generator=g) / 24)
+    ref = F.conv2d(x, wt, None, padding=1)
+    wp = pack(ops, L, wt.to(cuda), cin, cout, L.BF16, cuda)
+    out = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.BF16, inp=ops.view(nhwc(x).to(cuda, torch.bfloat16)), out=ops.view(out),
+                wpacked=wp)
+    got = nchw(out.float().cpu())
+    assert rel_l2(got, ref) < 1e-3
+    assert ((got - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all()
+    # bit-exact against rounding the fp32 reference wherever the fp32 sums agree to within half an ulp
+    assert (got == bf(ref)).float().mean() > 0.99
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+def test_conv3x3_dense_slices_residuals_and_dual_output(cuda, compute_name):
+    """In-place dense-block concat (channel slices of one 192-channel buffer), `x5*0.2 + x` then
+    `out*0.2 + x` (scunet_aaf6aa_arch.py:334-336,355-360), dual fp32 + compute-dtype stores."""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w = 2, 20, 36
+    g = torch.Generator().manual_seed(3)
+    buf = torch.randn(n, h, w, 192, generator=g)
+    if compute == L.BF16:
+        buf = bf(buf)
+    w2 = torch.randn(32, 96, 3, 3, generator=g) / 30
+    w5 = torch.randn(64, 192, 3, 3, generator=g) / 40
+    b2 = torch.randn(32, generator=g)
+    b5 = torch.randn(64, generator=g)
+    if compute == L.BF16:
+        w2, w5 = bf(w2), bf(w5)
+    r1 = torch.randn(n, h, w, 64, generator=g)
+    r2 = torch.randn(n, h, w, 64, generator=g)
+    x_nchw = nchw(buf)
+    ref2 = F.leaky_relu(F.conv2d(x_nchw[:, :96], w2, b2, padding=1), 0.2)
+    bd = buf.to(cuda, dt)
+    ops.conv3x3(n=n, h=h, w=w, cin=96, cout=32, compute=compute, inp=ops.view(bd, 0, 96), out=ops.view(bd, 96, 32),
+                wpacked=pack(ops, L, w2.to(cuda), 96, 32, compute, cuda), bias=b2.to(cuda), act=L.ACT_LRELU)
+    got2 = nchw(bd[..., 96:128].float().cpu())
+    tol = 2e-6 if compute == L.F32 else 1e-3
+    assert rel_l2(got2, ref2) < tol
+    # untouched channels stay untouched
+    assert torch.equal(bd[..., :96].float().cpu(), buf[..., :96]) and torch.equal(bd[..., 128:].float().cpu(), buf[..., 128:])
+    full = nchw(bd.float().cpu())
+    ref5 = (F.conv2d(full, w5, b5, padding=1) * 0.2 + nchw(r1)) * 0.2 + nchw(r2)
+    o32 = torch.empty(n, h, w, 64, dtype=torch.float32, device=cuda)
+    o2 = torch.zeros(n, h, w, 192, dtype=dt, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=192, cout=64, compute=compute, inp=ops.view(bd), out=ops.view(o32), out2=ops.view(o2, 0, 64),
+                out2_scale=0.5, wpacked=pack(ops, L, w5.to(cuda), 192, 64, compute, cuda), bias=b5.to(cuda), res1=ops.view(r1.to(cuda)),
+                scale1=0.2, res2=ops.view(r2.to(cuda)), scale2=0.2)
+    assert rel_l2(nchw(o32.cpu()), ref5) < 2e-6
+    assert rel_l2(nchw(o2[..., :64].float().cpu()), ref5 * 0.5) < tol
+    assert o2[..., 64:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+def test_conv3x3_nearest2x_and_replicate(cuda, compute_name):
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w, c = 1, 10, 18, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(c, c, 3, 3, generator=g) / 24
+    if compute == L.BF16:
+        x, wt = bf(x), bf(wt)
+    wp = pack(ops, L, wt.to(cuda), c, c, compute, cuda)
+    xd = nhwc(x).to(cuda, dt)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, None, padding=1)
+    out = torch.empty(n, 2 * h, 2 * w, c, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=2 * h, w=2 * w, cin=c, cout=c, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, in_mode=L.IN_NEAREST2X)
+    assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), wt, None)
+    out = torch.empty(n, h, w, c, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=c, cout=c, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, pad_mode=L.PAD_REPLICATE)
+    assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+def test_conv3x3_input_gradient_via_transposed_pack_and_mask(cuda, compute_name):
+    """dgrad = the same kernel on flipped/transposed weights; LeakyReLU derivative applied as an epilogue mask."""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w, cin, cout = 2, 13, 35, 96, 32
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / 30
+    gy = torch.randn(n, cout, h, w, generator=g)
+    pre = torch.randn(n, cin, h, w, generator=g)  # stands for the saved activation the mask is taken from
+    if compute == L.BF16:
+        wt, gy, pre = bf(wt), bf(gy), bf(pre)
+    ref = torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=1) * torch.where(pre > 0, 1.0, 0.2)
+    wp = pack(ops, L, wt.to(cuda), cout, cin, compute, cuda, transpose=True)
+    out = torch.empty(n, h, w, cin, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=compute, inp=ops.view(nhwc(gy).to(cuda, dt)), out=ops.view(out), wpacked=wp,
+                mask=ops.view(nhwc(pre).to(cuda, dt)), mask_slope=0.2)
+    assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 70, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 8)])
+def test_wgrad3x3(cuda, compute_name, shape):
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(21 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    gy = torch.randn(n, cout, h, w, generator=g)
+    if compute == L.BF16:
+        x, gy = bf(x), bf(gy)
+    ref_w = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), gy, padding=1)
+    ref_b = gy.sum(dim=(0, 2, 3))
+    ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4, dtype=torch.float32, device=cuda)
+    dw = torch.full((cout, cin, 3, 3), 7.0, device=cuda)
+    db = torch.full((cout,), 7.0, device=cuda)
+    kw = dict(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(nhwc(x).to(cuda, dt)), gy=ops.view(nhwc(gy).to(cuda, dt)),
+              dw=dw, db=db, workspace=ws)
+    ops.wgrad3x3(**kw)
+    tol = 3e-6 if compute == L.F32 else 3e-6
+    assert rel_l2(dw.cpu(), ref_w) < tol, rel_l2(dw.cpu(), ref_w)
+    assert rel_l2(db.cpu(), ref_b) < 3e-6
+    ops.wgrad3x3(**kw, accumulate=True)
+    assert rel_l2(dw.cpu(), 2 * ref_w) < tol
+    assert rel_l2(db.cpu(), 2 * ref_b) < 3e-6
+
+
+def test_wgrad3x3_is_bitwise_reproducible(cuda):
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cin, cout = 2, 40, 72, 64, 64
+    g = torch.Generator().manual_seed(2)
+    x = nhwc(torch.randn(n, cin, h, w, generator=g)).to(cuda, torch.bfloat16)
+    gy = nhwc(torch.randn(n, cout, h, w, generator=g)).to(cuda, torch.bfloat16)
+    ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4, dtype=torch.float32, device=cuda)
+    outs = []
+    for _ in range(3):
+        dw = torch.empty(cout, cin, 3, 3, device=cuda)
+        ops.wgrad3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.BF16, inp=ops.view(x), gy=ops.view(gy), dw=dw, db=None, workspace=ws)
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_layout_and_pool(cuda):
+    from trainner_redux_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(2, 3, 10, 14, generator=g)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for dt in (torch.float32, torch.bfloat16):
+        dst = torch.full((2, 10, 14, 8), 5.0, dtype=dt, device=cuda)
+        ops.nchw_to_nhwc(img.to(cuda), dst, mean, std)
+        ref = (img - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+        got = dst.float().cpu()
+        assert got[..., 3:].abs().max() == 0
+        assert rel_l2(nchw(got[..., :3]), ref) < (1e-6 if dt == torch.float32 else 3e-3)
+    back = torch.empty(2, 3, 10, 14, device=cuda)
+    d32 = torch.zeros(2, 10, 14, 4, device=cuda)
+    ops.nchw_to_nhwc(img.to(cuda), d32)
+    ops.nhwc_to_nchw(ops.view(d32), back)
+    assert torch.equal(back.cpu(), img)
+    # maxpool (+ fused relu) forward / backward against ATen
+    x = torch.randn(2, 16, 12, 20, generator=g)
+    x[0, 0, 0, :4] = 0.0  # ties
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(F.relu(xr), 2, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = nhwc(x).to(cuda)
+    yd = torch.empty(2, 6, 10, 16, device=cuda)
+    ops.maxpool2x2(ops.view(xd), ops.view(yd), 2, 12, 20, True)
+    assert torch.equal(nchw(yd.cpu()), y.detach())
+    gxd = torch.empty_like(xd)
+    ops.maxpool2x2_bwd(ops.view(xd), ops.view(nhwc(gy).to(cuda)), ops.view(gxd), 2, 12, 20, True)
+    assert torch.equal(nchw(gxd.cpu()), xr.grad)
+
+
+@pytest.mark.parametrize("kind", ["l1", "mse", "charbonnier"])
+@pytest.mark.parametrize("numel_shape", [(2, 3, 33, 47), (1, 3, 64, 64), (1, 1, 1, 3)])
+def test_pixel_loss(cuda, kind, numel_shape):
+    from oracle import losses as OL
+    from trainner_redux_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand(numel_shape, generator=g).requires_grad_(True)
+    tgt = torch.rand(numel_shape, generator=g)
+    with torch.no_grad():
+        tgt.view(-1)[0] = pred.view(-1)[0]  # exact-zero difference: sign(0) = 0
+    fn = {"l1": OL.l1, "mse": OL.mse, "charbonnier": OL.charbonnier}[kind]
+    code = {"l1": L.LOSS_L1, "mse": L.LOSS_MSE, "charbonnier": L.LOSS_CHARBONNIER}[kind]
+    ref = fn(pred, tgt) * 0.7
+    ref.backward()
+    out = torch.zeros(1, device=cuda)
+    grad = torch.empty(numel_shape, device=cuda)
+    ops.pixel_loss(code, pred.detach().to(cuda), tgt.to(cuda), 0.7, out, grad=grad)
+    assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-9
+    assert rel_l2(grad.cpu(), pred.grad) < 2e-6
+    ops.pixel_loss(code, pred.detach().to(cuda), tgt.to(cuda), 0.7, out, grad=grad, accumulate_loss=True, accumulate_grad=True)
+    assert abs(out.item() - 2 * ref.item()) <= 4e-6 * abs(ref.item()) + 1e-9
+    assert rel_l2(grad.cpu(), 2 * pred.grad) < 2e-6
+    # reference invariant (tests/test_losses/test_losses.py:114-128): black vs black is ~0
+    z = torch.zeros(numel_shape, device=cuda)
+    ops.pixel_loss(code, z, z, 1.0, out)
+    assert out.item() <= 1e-5
+
+
+def test_adamw_ema_clip_against_oracle(cuda):
+    from collections import OrderedDict
+
+    from oracle import step as OS
+    from trainner_redux_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    nel = 100003
+    p0 = torch.randn(nel, generator=g)
+    params = OrderedDict(p=p0.clone())
+    st = OS.AdamWState(params, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    ema = OS.EMAState(params, beta=0.999, power=0.75)
+    p = p0.to(cuda)
+    m = torch.zeros(nel, device=cuda)
+    v = torch.zeros(nel, device=cuda)
+    e = p.clone()
+    gn = torch.zeros(1, device=cuda)
+    ema_step = 0
+    for it in range(1, 6):
+        grad = torch.randn(nel, generator=g) * (3.0 if it % 2 else 0.001)
+        gref = OrderedDict(p=grad.clone())
+        total = OS.clip_grads_(gref, 1.0)
+        st.step(params, gref)
+        ema.update(params)
+        gd = grad.to(cuda)
+        ops.sumsq_norm(gd, gn)
+        assert abs(gn.item() - total.item()) < 1e-5 * total.item()
+        # ema decay for this step, host side (same schedule as the oracle)
+        s = ema_step
+        ema_step += 1
+        if s <= 0:
+            decay = 0.0
+        else:
+            ep = max(ema_step - 0 - 1, 0)
+            decay = 0.0 if ep <= 0 else min(max(1 - (1 + ep) ** -0.75, 0.0), 0.999)
+        ops.adamw_ema(p, gd, m, v, e, lr=2e-4, beta1=0.9, beta2=0.99, eps=1e-8, weight_decay=0.01, step=it, ema_decay=decay, clip=1.0,
+                      grad_norm=gn, zero_grad=True)
+        assert gd.abs().max().item() == 0
+        assert rel_l2(p.cpu(), params["p"]) < 1e-6
+        assert rel_l2(e.cpu(), ema.shadow["p"]) < 1e-6

@@ -1,0 +1,125 @@
+"""ctypes binding of libtrainner_hip.so (include/trainner_hip.h).
+
+The library is mandatory: there is no eager / PyTorch / CPU fallback anywhere in this package.
+`lib()` raises `RuntimeError` when the shared object is missing or its ABI version differs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+PAD_ZEROS, PAD_REPLICATE = 0, 1
+IN_DIRECT, IN_NEAREST2X = 0, 1
+LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("cstride", C.c_int32), ("coff", C.c_int32), ("c", C.c_int32)]
+
+
+class Conv3x3Desc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32),
+        ("compute", C.c_int32), ("in_mode", C.c_int32), ("pad_mode", C.c_int32), ("act", C.c_int32),
+        ("slope", C.c_float), ("scale1", C.c_float), ("scale2", C.c_float), ("mask_slope", C.c_float), ("out2_scale", C.c_float),
+        ("inp", View), ("out", View), ("out2", View), ("res1", View), ("res2", View), ("mask", View),
+        ("wpacked", C.c_void_p), ("bias", C.c_void_p),
+    ]
+
+
+class PackSeg(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p),
+        ("src_o", C.c_int32), ("src_i", C.c_int32),
+        ("o_off", C.c_int32), ("o_cnt", C.c_int32), ("i_off", C.c_int32), ("i_cnt", C.c_int32),
+        ("dst_cin", C.c_int32), ("dst_cout", C.c_int32),
+        ("dst_o_off", C.c_int32), ("dst_i_off", C.c_int32),
+        ("transpose", C.c_int32), ("compute", C.c_int32),
+        ("first", C.c_int64),
+    ]
+
+
+class Wgrad3x3Desc(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32),
+        ("compute", C.c_int32), ("in_mode", C.c_int32), ("pad_mode", C.c_int32), ("accumulate", C.c_int32),
+        ("inp", View), ("gy", View),
+        ("dw", C.c_void_p), ("db", C.c_void_p), ("partials", C.c_void_p), ("partials_bytes", C.c_size_t),
+    ]
+
+
+class AdamWDesc(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+        ("numel", C.c_int64),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("ema_decay", C.c_float), ("clip", C.c_float),
+        ("grad_norm", C.c_void_p), ("zero_grad", C.c_int32),
+    ]
+
+
+# every symbol include/trainner_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "tr_abi_version": (C.c_int, []),
+    "tr_last_error": (C.c_char_p, []),
+    "tr_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "tr_conv3x3": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
+    "tr_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]),
+    "tr_wgrad3x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_wgrad3x3": (C.c_int, [C.c_void_p, C.POINTER(Wgrad3x3Desc)]),
+    "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_nhwc_to_nchw_scaled": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "tr_scale_copy": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_float]),
+    "tr_maxpool2x2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_pixel_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float,
+                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tr_sumsq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "tr_adamw_ema": (C.c_int, [C.c_void_p, C.POINTER(AdamWDesc)]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the C-ABI library.  Fails loudly; never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+            "This package has no non-HIP execution path."
+        )
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:  # pragma: no cover
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = handle.tr_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().tr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"trainner_hip {what} failed (rc={rc}): {msg}")

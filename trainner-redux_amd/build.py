@@ -1,0 +1,52 @@
+"""Builds csrc/*.hip into libtrainner_hip.so (in-tree, next to this file) with hipcc for gfx950."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(HERE, "libtrainner_hip.so")
+SOURCES = ["common.hip", "conv3x3.hip", "pack.hip", "wgrad3x3.hip", "eltwise.hip", "loss.hip", "optim.hip"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "trainner_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", f"-I{INCLUDE}", f"-I{CSRC}",
+               "-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    if verbose:
+        print(f"built {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

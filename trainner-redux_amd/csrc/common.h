@@ -1,0 +1,117 @@
+// Shared helpers for libtrainner_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "trainner_hip.h"
+
+namespace tr {
+
+void set_error(const char* fmt, ...);
+
+#define TR_REQUIRE(cond, code, ...)                 \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::tr::set_error(__VA_ARGS__);           \
+            return (code);                          \
+        }                                           \
+    } while (0)
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+__host__ __device__ inline int esize(int dtype) { return dtype == TR_BF16 ? 2 : 4; }
+
+// ---- device-side scalar conversions -------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short b) {
+    return __uint_as_float(((unsigned)b) << 16);
+}
+// plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN preserving) on gfx950
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ float view_load(const tr_view& v, int64_t pix, int c) {
+    int64_t idx = pix * v.cstride + v.coff + c;
+    if (v.dtype == TR_BF16) return bf16_to_f32(((const unsigned short*)v.ptr)[idx]);
+    return ((const float*)v.ptr)[idx];
+}
+__device__ __forceinline__ void view_store(const tr_view& v, int64_t pix, int c, float x) {
+    int64_t idx = pix * v.cstride + v.coff + c;
+    if (v.dtype == TR_BF16) ((unsigned short*)v.ptr)[idx] = f32_to_bf16(x);
+    else ((float*)v.ptr)[idx] = x;
+}
+
+// 4 consecutive channels; `vec` = the view allows 4-element vector access at multiples of 4
+__device__ __forceinline__ float4 view_load4(const tr_view& v, int64_t pix, int c, bool vec) {
+    int64_t idx = pix * v.cstride + v.coff + c;
+    float4 r;
+    if (v.dtype == TR_BF16) {
+        const unsigned short* p = (const unsigned short*)v.ptr + idx;
+        if (vec) {
+            uint2 u = *(const uint2*)p;
+            r.x = __uint_as_float(u.x << 16); r.y = __uint_as_float(u.x & 0xffff0000u);
+            r.z = __uint_as_float(u.y << 16); r.w = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            r.x = bf16_to_f32(p[0]); r.y = bf16_to_f32(p[1]); r.z = bf16_to_f32(p[2]); r.w = bf16_to_f32(p[3]);
+        }
+    } else {
+        const float* p = (const float*)v.ptr + idx;
+        if (vec) r = *(const float4*)p;
+        else { r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3]; }
+    }
+    return r;
+}
+__device__ __forceinline__ void view_store4(const tr_view& v, int64_t pix, int c, float4 x, bool vec) {
+    int64_t idx = pix * v.cstride + v.coff + c;
+    if (v.dtype == TR_BF16) {
+        unsigned short* p = (unsigned short*)v.ptr + idx;
+        unsigned short a = f32_to_bf16(x.x), b = f32_to_bf16(x.y), c2 = f32_to_bf16(x.z), d = f32_to_bf16(x.w);
+        if (vec) { uint2 u; u.x = (unsigned)a | ((unsigned)b << 16); u.y = (unsigned)c2 | ((unsigned)d << 16); *(uint2*)p = u; }
+        else { p[0] = a; p[1] = b; p[2] = c2; p[3] = d; }
+    } else {
+        float* p = (float*)v.ptr + idx;
+        if (vec) *(float4*)p = x;
+        else { p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w; }
+    }
+}
+
+// host: can the view be accessed as aligned 4-channel vectors?
+inline bool view_vec4_ok(const tr_view& v) {
+    if (!v.ptr) return true;
+    int es = esize(v.dtype);
+    return (v.cstride % 4 == 0) && (v.coff % 4 == 0) && (((uintptr_t)v.ptr) % (4 * es) == 0);
+}
+// host: 16-byte chunk access (conv operand staging)
+inline bool view_vec16B_ok(const tr_view& v) {
+    int es = esize(v.dtype);
+    int per = 16 / es;
+    return (v.cstride % per == 0) && (v.coff % per == 0) && (((uintptr_t)v.ptr) % 16 == 0);
+}
+
+// packed conv operand geometry (must match pack.hip and conv3x3.hip)
+struct PackGeom {
+    int ck;       // channels per K-chunk: 32 (bf16) / 16 (f32) -> 64 bytes per row
+    int eps;      // elements per 16-byte slot: 8 / 4
+    int cgw;      // output channels per group: 32 or 64
+    int ncg;      // number of output-channel groups
+    int nchunks;  // number of K-chunks
+};
+__host__ __device__ inline PackGeom pack_geom(int cin, int cout, int compute) {
+    PackGeom g;
+    g.ck = compute == TR_BF16 ? 32 : 16;
+    g.eps = compute == TR_BF16 ? 8 : 4;
+    g.cgw = cout > 32 ? 64 : 32;
+    g.ncg = (cout + g.cgw - 1) / g.cgw;
+    g.nchunks = (cin + g.ck - 1) / g.ck;
+    return g;
+}
+
+}  // namespace tr

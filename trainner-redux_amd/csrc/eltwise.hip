@@ -1,0 +1,176 @@
+// Layout conversion and pooling kernels (HBM-bound; one pass, vectorised NHWC accesses).
+// Contract: include/trainner_hip.h.  Reference arithmetic replaced:
+//   img2tensor CHW float32 batches -> channels_last   traiNNer/models/sr_model.py:434-446
+//   (x - mean) / std                                  traiNNer/losses/perceptual_fp16_loss.py:322
+//   nn.MaxPool2d(2, 2) of torchvision VGG19 features  traiNNer/losses/perceptual_fp16_loss.py:12-50
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, int c_src, int64_t hw, int64_t npix,
+                                                            tr_view dst, float3 mean, float3 istd, int norm) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nb = p / hw, s = p - nb * hw;
+        const float* sp = src + nb * c_src * hw + s;
+        for (int c = 0; c < dst.c; ++c) {
+            float v = 0.f;
+            if (c < c_src) {
+                v = sp[(int64_t)c * hw];
+                if (norm) {
+                    const float m = c == 0 ? mean.x : (c == 1 ? mean.y : mean.z);
+                    const float is = c == 0 ? istd.x : (c == 1 ? istd.y : istd.z);
+                    v = (v - m) / is;   // `is` holds std here (division like the reference)
+                }
+            }
+            tr::view_store(dst, p, c, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tr_view src, float* __restrict__ dst, int c_dst, int64_t hw, int64_t npix,
+                                                            float3 scale, int use_scale, int accumulate) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nb = p / hw, s = p - nb * hw;
+        float* dp = dst + nb * c_dst * hw + s;
+        for (int c = 0; c < c_dst; ++c) {
+            float v = tr::view_load(src, p, c);
+            if (use_scale) v *= (c == 0 ? scale.x : (c == 1 ? scale.y : scale.z));
+            if (accumulate) v += dp[(int64_t)c * hw];
+            dp[(int64_t)c * hw] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_copy_kernel(tr_view in, tr_view out, int64_t npix, int c4, float scale, int vin, int vout) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int c = (int)(i - p * c4) * 4;
+        float4 v = tr::view_load4(in, p, c, vin);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        tr::view_store4(out, p, c, v, vout);
+    }
+}
+
+// one thread = one output pixel x 4 channels
+__global__ __launch_bounds__(256) void maxpool_kernel(tr_view in, tr_view out, int n, int hin, int win, int relu, int vin, int vout) {
+    const int ho = hin >> 1, wo = win >> 1, c4 = out.c >> 2;
+    const int64_t total = (int64_t)n * ho * wo * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % c4) * 4; t /= c4;
+        const int x = (int)(t % wo); t /= wo;
+        const int y = (int)(t % ho);
+        const int nb = (int)(t / ho);
+        const int64_t p00 = ((int64_t)nb * hin + 2 * y) * win + 2 * x;
+        float4 a = tr::view_load4(in, p00, c, vin), b = tr::view_load4(in, p00 + 1, c, vin);
+        float4 d = tr::view_load4(in, p00 + win, c, vin), e = tr::view_load4(in, p00 + win + 1, c, vin);
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x)); m.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+        m.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z)); m.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+        if (relu) { m.x = fmaxf(m.x, 0.f); m.y = fmaxf(m.y, 0.f); m.z = fmaxf(m.z, 0.f); m.w = fmaxf(m.w, 0.f); }
+        tr::view_store4(out, ((int64_t)nb * ho + y) * wo + x, c, m, vout);
+    }
+}
+
+__device__ __forceinline__ void route(float a, float b, float d, float e, float g, int relu, float& ga, float& gb, float& gd, float& ge) {
+    if (relu) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); d = fmaxf(d, 0.f); e = fmaxf(e, 0.f); }
+    // first maximal element in window scan order (ATen max_pool2d keeps the earliest index on ties)
+    int k = 0; float m = a;
+    if (b > m) { m = b; k = 1; }
+    if (d > m) { m = d; k = 2; }
+    if (e > m) { m = e; k = 3; }
+    if (relu && !(m > 0.f)) g = 0.f;   // ReLU gradient is 0 at and below 0 (threshold backward)
+    ga = k == 0 ? g : 0.f; gb = k == 1 ? g : 0.f; gd = k == 2 ? g : 0.f; ge = k == 3 ? g : 0.f;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(tr_view in, tr_view gout, tr_view gin, int n, int hin, int win, int relu,
+                                                           int vin, int vgo, int vgi) {
+    const int ho = hin >> 1, wo = win >> 1, c4 = gout.c >> 2;
+    const int64_t total = (int64_t)n * ho * wo * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % c4) * 4; t /= c4;
+        const int x = (int)(t % wo); t /= wo;
+        const int y = (int)(t % ho);
+        const int nb = (int)(t / ho);
+        const int64_t p00 = ((int64_t)nb * hin + 2 * y) * win + 2 * x;
+        const float4 a = tr::view_load4(in, p00, c, vin), b = tr::view_load4(in, p00 + 1, c, vin);
+        const float4 d = tr::view_load4(in, p00 + win, c, vin), e = tr::view_load4(in, p00 + win + 1, c, vin);
+        const float4 g = tr::view_load4(gout, ((int64_t)nb * ho + y) * wo + x, c, vgo);
+        float4 ga, gb, gd, ge;
+        route(a.x, b.x, d.x, e.x, g.x, relu, ga.x, gb.x, gd.x, ge.x);
+        route(a.y, b.y, d.y, e.y, g.y, relu, ga.y, gb.y, gd.y, ge.y);
+        route(a.z, b.z, d.z, e.z, g.z, relu, ga.z, gb.z, gd.z, ge.z);
+        route(a.w, b.w, d.w, e.w, g.w, relu, ga.w, gb.w, gd.w, ge.w);
+        tr::view_store4(gin, p00, c, ga, vgi); tr::view_store4(gin, p00 + 1, c, gb, vgi);
+        tr::view_store4(gin, p00 + win, c, gd, vgi); tr::view_store4(gin, p00 + win + 1, c, ge, vgi);
+    }
+}
+
+inline unsigned grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int tr_nchw_to_nhwc(void* stream, const float* src, int n, int c_src, int h, int w, tr_view dst,
+                               const float* mean3, const float* std3) {
+    TR_REQUIRE(src && dst.ptr && n > 0 && c_src > 0 && h > 0 && w > 0, TR_EINVAL, "tr_nchw_to_nhwc: bad arguments");
+    TR_REQUIRE(dst.coff + dst.c <= dst.cstride && dst.c >= c_src, TR_EINVAL, "tr_nchw_to_nhwc: view narrower than c_src=%d", c_src);
+    TR_REQUIRE((mean3 == nullptr) == (std3 == nullptr) && (!mean3 || c_src == 3), TR_EINVAL,
+               "tr_nchw_to_nhwc: mean/std need 3 source channels (host pointers)");
+    float3 m = make_float3(0, 0, 0), s = make_float3(1, 1, 1);
+    if (mean3) { m = make_float3(mean3[0], mean3[1], mean3[2]); s = make_float3(std3[0], std3[1], std3[2]); }
+    const int64_t npix = (int64_t)n * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, c_src, (int64_t)h * w, npix,
+                       dst, m, s, mean3 ? 1 : 0);
+    return tr::launch_status("tr_nchw_to_nhwc");
+}
+
+extern "C" int tr_nhwc_to_nchw(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w) {
+    TR_REQUIRE(src.ptr && dst && n > 0 && c_dst > 0 && src.c >= c_dst, TR_EINVAL, "tr_nhwc_to_nchw: bad arguments");
+    const int64_t npix = (int64_t)n * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, c_dst, (int64_t)h * w,
+                       npix, make_float3(1, 1, 1), 0, 0);
+    return tr::launch_status("tr_nhwc_to_nchw");
+}
+
+extern "C" int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w,
+                                      const float* inv_std3, int accumulate) {
+    TR_REQUIRE(src.ptr && dst && n > 0 && c_dst == 3 && src.c >= 3 && inv_std3, TR_EINVAL, "tr_nhwc_to_nchw_scaled: bad arguments");
+    const int64_t npix = (int64_t)n * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, c_dst, (int64_t)h * w,
+                       npix, make_float3(inv_std3[0], inv_std3[1], inv_std3[2]), 1, accumulate);
+    return tr::launch_status("tr_nhwc_to_nchw_scaled");
+}
+
+extern "C" int tr_scale_copy(void* stream, tr_view in, tr_view out, int64_t npix, float scale) {
+    TR_REQUIRE(in.ptr && out.ptr && npix > 0 && in.c == out.c && in.c % 4 == 0, TR_EINVAL,
+               "tr_scale_copy: views must have equal channel counts that are multiples of 4");
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(npix * (in.c / 4))), dim3(256), 0, (hipStream_t)stream, in, out, npix, in.c / 4,
+                       scale, (int)tr::view_vec4_ok(in), (int)tr::view_vec4_ok(out));
+    return tr::launch_status("tr_scale_copy");
+}
+
+extern "C" int tr_maxpool2x2(void* stream, tr_view in, tr_view out, int n, int h_in, int w_in, int relu_first) {
+    TR_REQUIRE(in.ptr && out.ptr && n > 0 && in.c == out.c && in.c % 4 == 0, TR_EINVAL, "tr_maxpool2x2: channel mismatch");
+    TR_REQUIRE(h_in % 2 == 0 && w_in % 2 == 0 && h_in > 0 && w_in > 0, TR_EUNSUPPORTED, "tr_maxpool2x2: odd spatial dims %dx%d", h_in, w_in);
+    const int64_t work = (int64_t)n * (h_in / 2) * (w_in / 2) * (in.c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, in, out, n, h_in, w_in, relu_first,
+                       (int)tr::view_vec4_ok(in), (int)tr::view_vec4_ok(out));
+    return tr::launch_status("tr_maxpool2x2");
+}
+
+extern "C" int tr_maxpool2x2_bwd(void* stream, tr_view in, tr_view gout, tr_view gin, int n, int h_in, int w_in, int relu_first) {
+    TR_REQUIRE(in.ptr && gout.ptr && gin.ptr && in.c == gout.c && in.c == gin.c && in.c % 4 == 0, TR_EINVAL,
+               "tr_maxpool2x2_bwd: channel mismatch");
+    TR_REQUIRE(h_in % 2 == 0 && w_in % 2 == 0 && h_in > 0 && w_in > 0, TR_EUNSUPPORTED, "tr_maxpool2x2_bwd: odd spatial dims");
+    const int64_t work = (int64_t)n * (h_in / 2) * (w_in / 2) * (in.c / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, in, gout, gin, n, h_in, w_in,
+                       relu_first, (int)tr::view_vec4_ok(in), (int)tr::view_vec4_ok(gout), (int)tr::view_vec4_ok(gin));
+    return tr::launch_status("tr_maxpool2x2_bwd");
+}

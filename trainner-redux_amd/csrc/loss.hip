@@ -1,0 +1,172 @@
+// Pixel-loss heads: l1 / mse / charbonnier, reduction 'mean', fused forward + d/dpred.
+// Contract: include/trainner_hip.h (tr_pixel_loss).  Reference arithmetic replaced:
+//   l1_loss / mse_loss / charbonnier_loss   traiNNer/losses/basic_loss.py:16-28
+//   mean reduction                          traiNNer/losses/loss_util.py:8-26
+// HBM-bound: 16-byte loads of pred and target, one 16-byte (or 8-byte bf16) grad store, a wave
+// shuffle + LDS block reduction, and a fixed-order second-stage sum (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    }
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ void elem(float d, float eps, float& val, float& dv) {
+    if (KIND == TR_LOSS_L1) {
+        val = fabsf(d);
+        dv = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    } else if (KIND == TR_LOSS_MSE) {
+        val = d * d;
+        dv = 2.f * d;
+    } else {
+        val = sqrtf(d * d + eps);
+        dv = d / val;
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const void* p, int dtype, int64_t i) {
+    if (dtype == TR_BF16) {
+        const uint2 u = *(const uint2*)((const unsigned short*)p + i);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    }
+    return *(const float4*)((const float*)p + i);
+}
+__device__ __forceinline__ float ld1(const void* p, int dtype, int64_t i) {
+    return dtype == TR_BF16 ? tr::bf16_to_f32(((const unsigned short*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st1(void* p, int dtype, int64_t i, float v, int acc) {
+    if (dtype == TR_BF16) {
+        unsigned short* q = (unsigned short*)p + i;
+        if (acc) v += tr::bf16_to_f32(*q);
+        *q = tr::f32_to_bf16(v);
+    } else {
+        float* q = (float*)p + i;
+        if (acc) v += *q;
+        *q = v;
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void pixel_loss_kernel(const void* __restrict__ pred, const void* __restrict__ target, int dtype,
+                                                          int64_t numel, float gscale, float eps, void* grad, int gdtype, int gacc,
+                                                          float* __restrict__ partials) {
+    __shared__ float sh[4];
+    float sum = 0.f;
+    const int64_t n4 = numel >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 p = ld4(pred, dtype, i * 4), t = ld4(target, dtype, i * 4);
+        float v0, v1, v2, v3, g0, g1, g2, g3;
+        elem<KIND>(p.x - t.x, eps, v0, g0); elem<KIND>(p.y - t.y, eps, v1, g1);
+        elem<KIND>(p.z - t.z, eps, v2, g2); elem<KIND>(p.w - t.w, eps, v3, g3);
+        sum += (v0 + v1) + (v2 + v3);
+        if (grad) {
+            st1(grad, gdtype, i * 4 + 0, g0 * gscale, gacc); st1(grad, gdtype, i * 4 + 1, g1 * gscale, gacc);
+            st1(grad, gdtype, i * 4 + 2, g2 * gscale, gacc); st1(grad, gdtype, i * 4 + 3, g3 * gscale, gacc);
+        }
+    }
+    // tail (numel % 4) handled by block 0
+    if (blockIdx.x == 0) {
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < numel; i += blockDim.x) {
+            float v, g;
+            elem<KIND>(ld1(pred, dtype, i) - ld1(target, dtype, i), eps, v, g);
+            sum += v;
+            if (grad) st1(grad, gdtype, i, g * gscale, gacc);
+        }
+    }
+    const float bs = block_sum(sum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bs;
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ partials, int nparts, float scale, float* out, int acc,
+                                                     int take_sqrt) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partials[i];
+    const float t = block_sum(s, sh);
+    if (threadIdx.x == 0) {
+        float r = take_sqrt ? sqrtf(t) : t * scale;
+        out[0] = acc ? out[0] + r : r;
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, int64_t numel, float* __restrict__ partials) {
+    __shared__ float sh[4];
+    float sum = 0.f;
+    const int64_t n4 = numel >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = *(const float4*)(x + i * 4);
+        sum += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < numel; i += blockDim.x) sum += x[i] * x[i];
+    const float bs = block_sum(sum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bs;
+}
+
+inline int blocks_for(int64_t numel) {
+    int64_t b = (numel / 4 + 255) / 256;
+    if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int tr_pixel_loss(void* stream, int kind, const void* pred, const void* target, int dtype, int64_t numel, float weight,
+                             float eps, float* loss_out, int accumulate_loss, void* grad, int grad_dtype, int accumulate_grad,
+                             float* partials) {
+    TR_REQUIRE(pred && target && loss_out && partials && numel > 0, TR_EINVAL, "tr_pixel_loss: bad arguments");
+    TR_REQUIRE(kind >= TR_LOSS_L1 && kind <= TR_LOSS_CHARBONNIER, TR_EINVAL, "tr_pixel_loss: unknown kind %d", kind);
+    TR_REQUIRE(((uintptr_t)pred) % 16 == 0 && ((uintptr_t)target) % 16 == 0, TR_EALIGN, "tr_pixel_loss: pred/target must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = blocks_for(numel);
+    const float gscale = weight / (float)numel;
+    switch (kind) {
+        case TR_LOSS_L1:
+            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_L1>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps, grad,
+                               grad_dtype, accumulate_grad, partials);
+            break;
+        case TR_LOSS_MSE:
+            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_MSE>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps, grad,
+                               grad_dtype, accumulate_grad, partials);
+            break;
+        default:
+            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_CHARBONNIER>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps,
+                               grad, grad_dtype, accumulate_grad, partials);
+    }
+    int rc = tr::launch_status("tr_pixel_loss");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, weight / (float)numel, loss_out, accumulate_loss, 0);
+    return tr::launch_status("tr_pixel_loss(finish)");
+}
+
+extern "C" int tr_sumsq(void* stream, const float* x, int64_t numel, float* norm_out, float* partials) {
+    TR_REQUIRE(x && norm_out && partials && numel > 0, TR_EINVAL, "tr_sumsq: bad arguments");
+    TR_REQUIRE(((uintptr_t)x) % 16 == 0, TR_EALIGN, "tr_sumsq: x must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = blocks_for(numel);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, x, numel, partials);
+    int rc = tr::launch_status("tr_sumsq");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, 1.f, norm_out, 0, 1);
+    return tr::launch_status("tr_sumsq(finish)");
+}

@@ -1,0 +1,333 @@
+// Weight / bias gradient of the 3x3 convolution on NHWC views, reduction over pixels on MFMA.
+//
+// Contract: include/trainner_hip.h (tr_wgrad3x3).  Replaces what autograd's conv backward
+// accumulates into Conv2d.weight.grad / .bias.grad at traiNNer/models/sr_model.py:681.
+//
+//   dW[co][tap][ci] = sum_p gy[p][co] * x[p + tap][ci]       GEMM: M = co, N = ci, K = pixels
+//
+// Mapping to gfx950 (DESIGN.md "wgrad kernel"):
+//   * grid = (pixel-tile slots, 32-channel ci chunks, cout groups); a workgroup of 3 waves walks
+//     its share of 8x32-pixel tiles and keeps dW[CG][ky][0..2][32 ci] in accumulators (wave = ky),
+//     so partial sums leave the chip once per workgroup, not once per tile;
+//   * K (pixels) is the strided axis of both NHWC operands, so bf16 fragments are fetched with
+//     ds_read_b64_tr_b16 (4 pixels x 16 channels transposed per 16-lane group); f32 fragments are
+//     one float per lane and need no transpose (v_mfma_f32_32x32x2_f32);
+//   * partials go to a caller workspace and a second kernel sums them in fixed slot order:
+//     bitwise reproducible, no float atomics.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int TW = 32, TH = 8, HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int NTHREADS = 192;
+constexpr int CKW = 32;   // input channels per workgroup
+
+struct WgArgs {
+    int n, h, w, hin, win;
+    int cin, cout;
+    int up, replicate;
+    tr_view in, gy;
+    float* partials;
+    int ntx, nty, ntiles, nslots, nchunks, ncg;
+};
+
+template <int CT, int NT>
+__global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
+    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int EPS = 16 / ES;
+    constexpr int CG = NT * 32;
+    constexpr int XPIX_BYTES = CKW * ES;                 // 64 (bf16) / 128 (f32)
+    constexpr int XSLOTS = XPIX_BYTES / 16;
+    constexpr int GPIX_BYTES = CG * ES;
+    constexpr int GSLOTS = GPIX_BYTES / 16;
+    constexpr int X_BYTES = HALO_H * HALO_W * XPIX_BYTES;
+    constexpr bool GSWZ = (CT == TR_BF16 && NT == 2);    // 128-byte bf16 rows: swap 64-byte halves on odd pixel pairs
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xl = smem;
+    char* gl = smem + X_BYTES;
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63, ky = tid >> 6;
+    const int lr = l & 31, lh = l >> 5;
+    const int slot = blockIdx.x, chunk = blockIdx.y, cg = blockIdx.z;
+
+    f32x16 acc[3][NT];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[k][t][i] = 0.f;
+
+    const char* in_base = (const char*)a.in.ptr;
+    const char* gy_base = (const char*)a.gy.ptr;
+    const int64_t in_pix_bytes = (int64_t)a.in.cstride * ES;
+    const int64_t gy_pix_bytes = (int64_t)a.gy.cstride * ES;
+
+    for (int tile = slot; tile < a.ntiles; tile += a.nslots) {
+        int t = tile;
+        const int tx = t % a.ntx; t /= a.ntx;
+        const int ty = t % a.nty;
+        const int nb = t / a.nty;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();
+        for (int it = tid; it < HALO_H * HALO_W * XSLOTS; it += NTHREADS) {
+            const int pp = it / XSLOTS, s = it - pp * XSLOTS;
+            const int py = pp / HALO_W, px = pp - py * HALO_W;
+            int oy = y0 + py - 1, ox = x0 + px - 1;
+            bool ok = (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
+            if (a.replicate) {
+                oy = min(max(oy, 0), a.h - 1);
+                ox = min(max(ox, 0), a.w - 1);
+                ok = true;
+            }
+            const int c0 = chunk * CKW + s * EPS;
+            ok = ok & (c0 + EPS <= a.in.c);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t pix = ((int64_t)nb * a.hin + (oy >> a.up)) * a.win + (ox >> a.up);
+                v = *(const uint4*)(in_base + pix * in_pix_bytes + (int64_t)(a.in.coff + c0) * ES);
+            }
+            *(uint4*)(xl + pp * XPIX_BYTES + s * 16) = v;
+        }
+        for (int it = tid; it < TH * TW * GSLOTS; it += NTHREADS) {
+            const int gp = it / GSLOTS, s = it - gp * GSLOTS;
+            const int py = gp >> 5, px = gp & 31;
+            const int oy = y0 + py, ox = x0 + px;
+            const int c0 = cg * CG + s * EPS;
+            const bool ok = (oy < a.h) & (ox < a.w) & (c0 + EPS <= a.gy.c);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
+                v = *(const uint4*)(gy_base + pix * gy_pix_bytes + (int64_t)(a.gy.coff + c0) * ES);
+            }
+            int so = s * 16;
+            if (GSWZ) so ^= ((gp >> 1) & 1) << 6;
+            *(uint4*)(gl + gp * GPIX_BYTES + so) = v;
+        }
+        __syncthreads();
+
+        if constexpr (CT == TR_BF16) {
+            const int li = l & 15, q = li >> 2, p = li & 3;
+            const int i0 = ((l >> 4) & 1) * 16;
+#pragma unroll 2
+            for (int r = 0; r < TH; ++r) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    bf16x8 af[NT];
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2) {
+                        s16x4 lo, hi;
+                        {
+                            const int gp = r * 32 + kb * 16 + 8 * lh + q;
+                            int bo = (t2 * 32 + i0 + 4 * p) * 2;
+                            if (GSWZ) bo ^= ((gp >> 1) & 1) << 6;
+                            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gl + gp * GPIX_BYTES + bo));
+                        }
+                        {
+                            const int gp = r * 32 + kb * 16 + 8 * lh + 4 + q;
+                            int bo = (t2 * 32 + i0 + 4 * p) * 2;
+                            if (GSWZ) bo ^= ((gp >> 1) & 1) << 6;
+                            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gl + gp * GPIX_BYTES + bo));
+                        }
+                        af[t2] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int hp = (r + ky) * HALO_W + kb * 16 + kx + 8 * lh + q;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(xl + hp * XPIX_BYTES + (i0 + 4 * p) * 2));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(xl + (hp + 4) * XPIX_BYTES + (i0 + 4 * p) * 2));
+                        const bf16x8 bf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                        for (int t2 = 0; t2 < NT; ++t2)
+                            acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t2], bf, acc[kx][t2], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            for (int r = 0; r < TH; ++r) {
+#pragma unroll 4
+                for (int kp = 0; kp < 16; ++kp) {
+                    float af[NT];
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2)
+                        af[t2] = *(const float*)(gl + (r * 32 + kp * 2 + lh) * GPIX_BYTES + (t2 * 32 + lr) * 4);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float bf = *(const float*)(xl + ((r + ky) * HALO_W + kp * 2 + lh + kx) * XPIX_BYTES + lr * 4);
+#pragma unroll
+                        for (int t2 = 0; t2 < NT; ++t2)
+                            acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t2], bf, acc[kx][t2], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // partial block: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
+    float* dst = a.partials + (((int64_t)slot * a.nchunks + chunk) * a.ncg + cg) * (CG * 9 * CKW);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = t2 * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                dst[(co * 9 + ky * 3 + kx) * CKW + lr] = acc[kx][t2][reg];
+            }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate) {
+    // one thread per (co, tap, ci) with ci fastest so partial reads are coalesced
+    const int64_t total = (int64_t)cout * 9 * cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const int tap = (int)((i / cin) % 9);
+        const int co = (int)(i / ((int64_t)cin * 9));
+        const int chunk = ci / CKW, cil = ci - chunk * CKW;
+        const int cg = co / cgw, col = co - cg * cgw;
+        const int64_t blk = (int64_t)cgw * 9 * CKW;
+        const float* p = partials + ((int64_t)chunk * ncg + cg) * blk + ((int64_t)col * 9 + tap) * CKW + cil;
+        const int64_t stride = (int64_t)nchunks * ncg * blk;
+        float s = 0.f;
+        for (int k = 0; k < nslots; ++k) s += p[k * stride];
+        float* o = dw + ((int64_t)co * cin + ci) * 9 + tap;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+// bias gradient: column sums of gy over all pixels
+__global__ __launch_bounds__(256) void colsum_kernel(tr_view gy, int64_t npix, int c, float* __restrict__ partials) {
+    // thread = (pixel lane, channel); block covers a contiguous pixel range
+    extern __shared__ float sh[];
+    const int lanes = 256 / c > 0 ? 256 / c : 1;       // pixel lanes per block (c <= 256)
+    const int ch = threadIdx.x % c, pl = threadIdx.x / c;
+    float s = 0.f;
+    if (pl < lanes) {
+        const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+        const int64_t b = (int64_t)blockIdx.x * per, e = min(b + per, npix);
+        for (int64_t p = b + pl; p < e; p += lanes) s += tr::view_load(gy, p, ch);
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < c) {
+        float t = 0.f;
+        for (int k = 0; k < lanes; ++k) t += sh[k * c + threadIdx.x];
+        partials[(int64_t)blockIdx.x * c + threadIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partials, int nblocks, int c, float* __restrict__ db,
+                                                             int accumulate) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    float s = 0.f;
+    for (int k = 0; k < nblocks; ++k) s += partials[(int64_t)k * c + ch];
+    db[ch] = accumulate ? db[ch] + s : s;
+}
+
+struct Plan {
+    int ntx, nty, ntiles, nslots, nchunks, ncg, cgw;
+    size_t dw_floats, db_blocks, db_floats;
+};
+
+Plan make_plan(int n, int h, int w, int cin, int cout) {
+    Plan p;
+    p.ntx = (w + TW - 1) / TW;
+    p.nty = (h + TH - 1) / TH;
+    p.ntiles = p.ntx * p.nty * n;
+    p.nchunks = (cin + CKW - 1) / CKW;
+    p.cgw = cout > 32 ? 64 : 32;
+    p.ncg = (cout + p.cgw - 1) / p.cgw;
+    int target = 1024 / (p.nchunks * p.ncg);
+    if (target < 1) target = 1;
+    p.nslots = p.ntiles < target ? p.ntiles : target;
+    p.dw_floats = (size_t)p.nslots * p.nchunks * p.ncg * p.cgw * 9 * CKW;
+    p.db_blocks = 256;
+    p.db_floats = p.db_blocks * (size_t)cout;
+    return p;
+}
+
+template <int CT, int NT>
+int launch_wgrad(hipStream_t st, const WgArgs& a) {
+    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr size_t lds = (size_t)HALO_H * HALO_W * CKW * ES + (size_t)TH * TW * NT * 32 * ES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_kernel<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<CT, NT>), dim3(a.nslots, a.nchunks, a.ncg), dim3(NTHREADS), lds, st, a);
+    return tr::launch_status("tr_wgrad3x3");
+}
+
+}  // namespace
+
+extern "C" size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    const Plan p = make_plan(n, h, w, cin, cout);
+    return (p.dw_floats + p.db_floats) * sizeof(float);
+}
+
+extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
+    TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_wgrad3x3: null descriptor");
+    TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, TR_EINVAL, "tr_wgrad3x3: bad dims");
+    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16, TR_EINVAL, "tr_wgrad3x3: bad compute dtype");
+    TR_REQUIRE(d->in.ptr && d->gy.ptr && d->dw && d->partials, TR_EINVAL, "tr_wgrad3x3: in/gy/dw/partials must be set");
+    TR_REQUIRE(d->in.dtype == d->compute && d->gy.dtype == d->compute, TR_EUNSUPPORTED,
+               "tr_wgrad3x3: operand dtypes must equal the compute dtype");
+    const int eps = d->compute == TR_BF16 ? 8 : 4;
+    TR_REQUIRE(d->in.c % eps == 0 && d->gy.c % eps == 0 && d->in.c >= d->cin && d->gy.c >= d->cout, TR_EALIGN,
+               "tr_wgrad3x3: view channel counts must be multiples of %d covering cin/cout", eps);
+    TR_REQUIRE(tr::view_vec16B_ok(d->in) && tr::view_vec16B_ok(d->gy), TR_EALIGN, "tr_wgrad3x3: views are not 16-byte sliceable");
+    TR_REQUIRE(d->in.coff + d->in.c <= d->in.cstride && d->gy.coff + d->gy.c <= d->gy.cstride, TR_EINVAL, "tr_wgrad3x3: view exceeds its buffer");
+    TR_REQUIRE(d->in_mode == TR_IN_DIRECT || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL, "tr_wgrad3x3: nearest-2x input needs even dims");
+    const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout);
+    TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
+               "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
+    TR_REQUIRE(d->db == nullptr || d->cout <= 256, TR_EUNSUPPORTED, "tr_wgrad3x3: bias gradient supports cout <= 256");
+
+    WgArgs a;
+    a.n = d->n; a.h = d->h; a.w = d->w;
+    a.up = d->in_mode == TR_IN_NEAREST2X ? 1 : 0;
+    a.hin = d->h >> a.up; a.win = d->w >> a.up;
+    a.cin = d->cin; a.cout = d->cout;
+    a.replicate = d->pad_mode == TR_PAD_REPLICATE;
+    a.in = d->in; a.gy = d->gy;
+    a.partials = d->partials;
+    a.ntx = p.ntx; a.nty = p.nty; a.ntiles = p.ntiles; a.nslots = p.nslots; a.nchunks = p.nchunks; a.ncg = p.ncg;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2>(st, a) : launch_wgrad<TR_BF16, 1>(st, a);
+    else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2>(st, a) : launch_wgrad<TR_F32, 1>(st, a);
+    if (rc) return rc;
+    {
+        const int64_t total = (int64_t)d->cout * 9 * d->cin;
+        int64_t b = (total + 255) / 256;
+        if (b > 2048) b = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots, p.nchunks,
+                           p.ncg, p.cgw, d->accumulate);
+        rc = tr::launch_status("tr_wgrad3x3(reduce)");
+        if (rc) return rc;
+    }
+    if (d->db) {
+        float* dbp = d->partials + p.dw_floats;
+        const int64_t npix = (int64_t)d->n * d->h * d->w;
+        int nb = (int)p.db_blocks;
+        if (npix < nb) nb = (int)npix;
+        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 256 * sizeof(float), st, d->gy, npix, d->cout, dbp);
+        rc = tr::launch_status("tr_wgrad3x3(colsum)");
+        if (rc) return rc;
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->cout + 255) / 256), dim3(256), 0, st, dbp, nb, d->cout, d->db, d->accumulate);
+        rc = tr::launch_status("tr_wgrad3x3(colsum finish)");
+    }
+    return rc;
+}

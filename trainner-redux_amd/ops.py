@@ -1,0 +1,212 @@
+"""Thin tensor-level wrappers over the C ABI (device pointers + current HIP stream).
+
+PyTorch is used for device memory and streams only; every function here launches hand-written
+HIP kernels from libtrainner_hip.so on `torch.cuda.current_stream()` and never computes with ATen.
+NHWC activations are torch tensors of shape (N, H, W, C), contiguous, dtype float32 or bfloat16.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dtype}; the HIP path handles float32 and bfloat16") from None
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.bfloat16 if code == L.BF16 else torch.float32
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("trainner_redux_amd ops run on the GPU only (tensor is on %s)" % t.device)
+
+
+def view(t: torch.Tensor | None, coff: int = 0, c: int | None = None) -> L.View:
+    """Channel-slice view of an NHWC tensor (last dim = channels, contiguous)."""
+    if t is None:
+        return L.View(None, 0, 0, 0, 0)
+    if not t.is_contiguous():
+        raise ValueError("NHWC buffer must be contiguous")
+    cs = t.shape[-1]
+    c = cs - coff if c is None else c
+    if coff < 0 or c <= 0 or coff + c > cs:
+        raise ValueError(f"bad channel slice [{coff}, {coff + c}) of {cs}")
+    return L.View(t.data_ptr(), dt_code(t.dtype), cs, coff, c)
+
+
+NULL_VIEW = L.View(None, 0, 0, 0, 0)
+
+
+def packed_bytes(cin: int, cout: int, compute: int) -> int:
+    return int(L.lib().tr_conv3x3_packed_bytes(cin, cout, compute))
+
+
+def conv3x3(*, n, h, w, cin, cout, compute, inp: L.View, out: L.View, wpacked: torch.Tensor, bias: torch.Tensor | None = None,
+            in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, act=L.ACT_NONE, slope=0.2, res1: L.View = NULL_VIEW, scale1=1.0,
+            res2: L.View = NULL_VIEW, scale2=1.0, mask: L.View = NULL_VIEW, mask_slope=0.2, out2: L.View = NULL_VIEW, out2_scale=1.0):
+    d = L.Conv3x3Desc()
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.compute, d.in_mode, d.pad_mode, d.act = compute, in_mode, pad_mode, act
+    d.slope, d.scale1, d.scale2, d.mask_slope, d.out2_scale = slope, scale1, scale2, mask_slope, out2_scale
+    d.inp, d.out, d.out2, d.res1, d.res2, d.mask = inp, out, out2, res1, res2, mask
+    d.wpacked = wpacked.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    L.check(L.lib().tr_conv3x3(stream_ptr(), C.byref(d)), "tr_conv3x3")
+
+
+class PackPlan:
+    """A device-resident segment table: one launch re-packs every conv operand of a network."""
+
+    def __init__(self, device):
+        self.device = device
+        self.segs: list[L.PackSeg] = []
+        self.total = 0
+        self._dev = None
+        self._keep = []
+
+    def add(self, src: torch.Tensor, dst: torch.Tensor, dst_cin: int, dst_cout: int, compute: int, *, o_off=0, o_cnt=None, i_off=0,
+            i_cnt=None, dst_o_off=0, dst_i_off=0, transpose=False):
+        assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4 and src.shape[2:] == (3, 3)
+        so, si = src.shape[0], src.shape[1]
+        o_cnt = so - o_off if o_cnt is None else o_cnt
+        i_cnt = si - i_off if i_cnt is None else i_cnt
+        s = L.PackSeg(src.data_ptr(), dst.data_ptr(), so, si, o_off, o_cnt, i_off, i_cnt, dst_cin, dst_cout, dst_o_off, dst_i_off,
+                      1 if transpose else 0, compute, self.total)
+        self.segs.append(s)
+        self.total += o_cnt * i_cnt * 9
+        self._keep.append((src, dst))
+        self._dev = None
+
+    def finalize(self):
+        arr = (L.PackSeg * len(self.segs))(*self.segs)
+        raw = bytes(arr)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self._dev = host.to(self.device)
+        return self
+
+    def run(self):
+        if not self.segs:
+            return
+        if self._dev is None:
+            self.finalize()
+        L.check(L.lib().tr_pack_conv3x3(stream_ptr(), self._dev.data_ptr(), len(self.segs), self.total), "tr_pack_conv3x3")
+
+
+def wgrad_workspace_bytes(n, h, w, cin, cout) -> int:
+    return int(L.lib().tr_wgrad3x3_workspace_bytes(n, h, w, cin, cout))
+
+
+def wgrad3x3(*, n, h, w, cin, cout, compute, inp: L.View, gy: L.View, dw: torch.Tensor, db: torch.Tensor | None, workspace: torch.Tensor,
+             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, accumulate=False):
+    d = L.Wgrad3x3Desc()
+    d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
+    d.compute, d.in_mode, d.pad_mode, d.accumulate = compute, in_mode, pad_mode, 1 if accumulate else 0
+    d.inp, d.gy = inp, gy
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * 9
+    d.dw = dw.data_ptr()
+    d.db = db.data_ptr() if db is not None else None
+    d.partials = workspace.data_ptr()
+    d.partials_bytes = workspace.numel() * workspace.element_size()
+    L.check(L.lib().tr_wgrad3x3(stream_ptr(), C.byref(d)), "tr_wgrad3x3")
+
+
+def _f3(vals):
+    return (C.c_float * 3)(*[float(v) for v in vals])
+
+
+def nchw_to_nhwc(src: torch.Tensor, dst: torch.Tensor, mean=None, std=None, dst_view: L.View | None = None):
+    _need_cuda(src, dst)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4
+    n, c, h, w = src.shape
+    v = dst_view if dst_view is not None else view(dst)
+    m = _f3(mean) if mean is not None else None
+    s = _f3(std) if std is not None else None
+    L.check(L.lib().tr_nchw_to_nhwc(stream_ptr(), src.data_ptr(), n, c, h, w, v, m, s), "tr_nchw_to_nhwc")
+
+
+def nhwc_to_nchw(src_view: L.View, dst: torch.Tensor):
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 4
+    n, c, h, w = dst.shape
+    L.check(L.lib().tr_nhwc_to_nchw(stream_ptr(), src_view, dst.data_ptr(), n, c, h, w), "tr_nhwc_to_nchw")
+
+
+def nhwc_to_nchw_scaled(src_view: L.View, dst: torch.Tensor, inv_std, accumulate: bool):
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 4
+    n, c, h, w = dst.shape
+    L.check(L.lib().tr_nhwc_to_nchw_scaled(stream_ptr(), src_view, dst.data_ptr(), n, c, h, w, _f3(inv_std), 1 if accumulate else 0),
+            "tr_nhwc_to_nchw_scaled")
+
+
+def scale_copy(inp: L.View, out: L.View, npix: int, scale: float):
+    L.check(L.lib().tr_scale_copy(stream_ptr(), inp, out, npix, scale), "tr_scale_copy")
+
+
+def maxpool2x2(inp: L.View, out: L.View, n, h_in, w_in, relu_first: bool):
+    L.check(L.lib().tr_maxpool2x2(stream_ptr(), inp, out, n, h_in, w_in, 1 if relu_first else 0), "tr_maxpool2x2")
+
+
+def maxpool2x2_bwd(inp: L.View, gout: L.View, gin: L.View, n, h_in, w_in, relu_first: bool):
+    L.check(L.lib().tr_maxpool2x2_bwd(stream_ptr(), inp, gout, gin, n, h_in, w_in, 1 if relu_first else 0), "tr_maxpool2x2_bwd")
+
+
+_partials: dict = {}
+
+
+def scratch(device, nfloats: int = 4096) -> torch.Tensor:
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    t = _partials.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 4096), dtype=torch.float32, device=device)
+        _partials[key] = t
+    return t
+
+
+def pixel_loss(kind: int, pred: torch.Tensor, target: torch.Tensor, weight: float, loss_out: torch.Tensor, *, eps: float = 1e-12,
+               accumulate_loss=False, grad: torch.Tensor | None = None, accumulate_grad=False):
+    _need_cuda(pred, target, loss_out, grad)
+    assert pred.shape == target.shape and pred.dtype == target.dtype and pred.is_contiguous() and target.is_contiguous()
+    assert loss_out.dtype == torch.float32
+    if grad is not None:
+        assert grad.is_contiguous() and grad.numel() == pred.numel()
+    L.check(L.lib().tr_pixel_loss(stream_ptr(), kind, pred.data_ptr(), target.data_ptr(), dt_code(pred.dtype), pred.numel(), weight, eps,
+                                  loss_out.data_ptr(), 1 if accumulate_loss else 0, grad.data_ptr() if grad is not None else None,
+                                  dt_code(grad.dtype) if grad is not None else 0, 1 if accumulate_grad else 0,
+                                  scratch(pred.device).data_ptr()), "tr_pixel_loss")
+
+
+def sumsq_norm(x: torch.Tensor, out: torch.Tensor):
+    _need_cuda(x, out)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    L.check(L.lib().tr_sumsq(stream_ptr(), x.data_ptr(), x.numel(), out.data_ptr(), scratch(x.device).data_ptr()), "tr_sumsq")
+
+
+def adamw_ema(p, g, m, v, ema, *, lr, beta1, beta2, eps, weight_decay, step: int, ema_decay: float = 1.0, clip: float = 0.0,
+              grad_norm: torch.Tensor | None = None, zero_grad=True):
+    _need_cuda(p, g, m, v, ema)
+    d = L.AdamWDesc()
+    d.p, d.g, d.m, d.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+    d.ema = ema.data_ptr() if ema is not None else None
+    d.numel = p.numel()
+    d.lr, d.beta1, d.beta2, d.eps, d.weight_decay = lr, beta1, beta2, eps, weight_decay
+    d.bias_corr1 = 1.0 - beta1 ** step
+    d.bias_corr2 = 1.0 - beta2 ** step
+    d.ema_decay = ema_decay
+    d.clip = clip
+    d.grad_norm = grad_norm.data_ptr() if grad_norm is not None else None
+    d.zero_grad = 1 if zero_grad else 0
+    L.check(L.lib().tr_adamw_ema(stream_ptr(), C.byref(d)), "tr_adamw_ema")
