@@ -58,7 +58,8 @@ def test_conv3x3_forward(cuda, compute_name, shape):
     xd = nhwc(x).to(cuda, dt)
     wp = pack(ops, L, wt.to(cuda), cin, cout, compute, cuda)
     out = torch.empty(n, h, w, cout, dtype=torch.float32, device=cuda)
-    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=b.to(cuda),
+    bd = b.to(cuda)  # NOTE: ops.view()/data_ptr() do not keep tensors alive -- every device operand is a named variable
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bd,
                 act=L.ACT_LRELU, slope=0.2)
     got = nchw(out.cpu())
     assert rel_l2(got, ref) < 2e-6, rel_l2(got, ref)
@@ -74,11 +75,14 @@ def test_conv3x3_bf16_output_rounding(cuda):
     ref = F.conv2d(x, wt, None, padding=1)
     wp = pack(ops, L, wt.to(cuda), cin, cout, L.BF16, cuda)
     out = torch.empty(n, h, w, cout, dtype=torch.bfloat16, device=cuda)
-    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.BF16, inp=ops.view(nhwc(x).to(cuda, torch.bfloat16)), out=ops.view(out),
-                wpacked=wp)
+    xd = nhwc(x).to(cuda, torch.bfloat16)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.BF16, inp=ops.view(xd), out=ops.view(out), wpacked=wp)
     got = nchw(out.float().cpu())
-    assert rel_l2(got, ref) < 1e-3
+    # one RNE rounding to bf16 is by itself 2^-9/sqrt(3)-ish ~ 1.7e-3 rel-L2 against the unrounded fp32 value ...
+    assert rel_l2(got, ref) < 2.5e-3
     assert ((got - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all()
+    # ... so the meaningful check is against the oracle rounded the same way: <= 1e-3 (in fact ~1e-5: rare 1-ulp flips)
+    assert rel_l2(got, bf(ref)) < 1e-3
     # bit-exact against rounding the fp32 reference wherever the fp32 sums agree to within half an ulp
     assert (got == bf(ref)).float().mean() > 0.99
 
@@ -107,11 +111,13 @@ def test_conv3x3_dense_slices_residuals_and_dual_output(cuda, compute_name):
     x_nchw = nchw(buf)
     ref2 = F.leaky_relu(F.conv2d(x_nchw[:, :96], w2, b2, padding=1), 0.2)
     bd = buf.to(cuda, dt)
+    wp2, wp5 = pack(ops, L, w2.to(cuda), 96, 32, compute, cuda), pack(ops, L, w5.to(cuda), 192, 64, compute, cuda)
+    b2d, b5d, r1d, r2d = b2.to(cuda), b5.to(cuda), r1.to(cuda), r2.to(cuda)
     ops.conv3x3(n=n, h=h, w=w, cin=96, cout=32, compute=compute, inp=ops.view(bd, 0, 96), out=ops.view(bd, 96, 32),
-                wpacked=pack(ops, L, w2.to(cuda), 96, 32, compute, cuda), bias=b2.to(cuda), act=L.ACT_LRELU)
+                wpacked=wp2, bias=b2d, act=L.ACT_LRELU)
     got2 = nchw(bd[..., 96:128].float().cpu())
     tol = 2e-6 if compute == L.F32 else 1e-3
-    assert rel_l2(got2, ref2) < tol
+    assert rel_l2(got2, ref2 if compute == L.F32 else bf(ref2)) < tol
     # untouched channels stay untouched
     assert torch.equal(bd[..., :96].float().cpu(), buf[..., :96]) and torch.equal(bd[..., 128:].float().cpu(), buf[..., 128:])
     full = nchw(bd.float().cpu())
@@ -119,10 +125,9 @@ def test_conv3x3_dense_slices_residuals_and_dual_output(cuda, compute_name):
     o32 = torch.empty(n, h, w, 64, dtype=torch.float32, device=cuda)
     o2 = torch.zeros(n, h, w, 192, dtype=dt, device=cuda)
     ops.conv3x3(n=n, h=h, w=w, cin=192, cout=64, compute=compute, inp=ops.view(bd), out=ops.view(o32), out2=ops.view(o2, 0, 64),
-                out2_scale=0.5, wpacked=pack(ops, L, w5.to(cuda), 192, 64, compute, cuda), bias=b5.to(cuda), res1=ops.view(r1.to(cuda)),
-                scale1=0.2, res2=ops.view(r2.to(cuda)), scale2=0.2)
+                out2_scale=0.5, wpacked=wp5, bias=b5d, res1=ops.view(r1d), scale1=0.2, res2=ops.view(r2d), scale2=0.2)
     assert rel_l2(nchw(o32.cpu()), ref5) < 2e-6
-    assert rel_l2(nchw(o2[..., :64].float().cpu()), ref5 * 0.5) < tol
+    assert rel_l2(nchw(o2[..., :64].float().cpu()), ref5 * 0.5 if compute == L.F32 else bf(ref5 * 0.5)) < tol
     assert o2[..., 64:].abs().max().item() == 0
 
 
@@ -168,8 +173,9 @@ def test_conv3x3_input_gradient_via_transposed_pack_and_mask(cuda, compute_name)
     ref = torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=1) * torch.where(pre > 0, 1.0, 0.2)
     wp = pack(ops, L, wt.to(cuda), cout, cin, compute, cuda, transpose=True)
     out = torch.empty(n, h, w, cin, dtype=torch.float32, device=cuda)
-    ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=compute, inp=ops.view(nhwc(gy).to(cuda, dt)), out=ops.view(out), wpacked=wp,
-                mask=ops.view(nhwc(pre).to(cuda, dt)), mask_slope=0.2)
+    gyd, pred = nhwc(gy).to(cuda, dt), nhwc(pre).to(cuda, dt)
+    ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=compute, inp=ops.view(gyd), out=ops.view(out), wpacked=wp,
+                mask=ops.view(pred), mask_slope=0.2)
     assert rel_l2(nchw(out.cpu()), ref) < 2e-6
 
 
@@ -191,8 +197,8 @@ def test_wgrad3x3(cuda, compute_name, shape):
     ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4, dtype=torch.float32, device=cuda)
     dw = torch.full((cout, cin, 3, 3), 7.0, device=cuda)
     db = torch.full((cout,), 7.0, device=cuda)
-    kw = dict(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(nhwc(x).to(cuda, dt)), gy=ops.view(nhwc(gy).to(cuda, dt)),
-              dw=dw, db=db, workspace=ws)
+    xd, gyd = nhwc(x).to(cuda, dt), nhwc(gy).to(cuda, dt)
+    kw = dict(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), gy=ops.view(gyd), dw=dw, db=db, workspace=ws)
     ops.wgrad3x3(**kw)
     tol = 3e-6 if compute == L.F32 else 3e-6
     assert rel_l2(dw.cpu(), ref_w) < tol, rel_l2(dw.cpu(), ref_w)
@@ -226,14 +232,15 @@ def test_layout_and_pool(cuda):
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
     for dt in (torch.float32, torch.bfloat16):
         dst = torch.full((2, 10, 14, 8), 5.0, dtype=dt, device=cuda)
-        ops.nchw_to_nhwc(img.to(cuda), dst, mean, std)
+        imgd = img.to(cuda)
+        ops.nchw_to_nhwc(imgd, dst, mean, std)
         ref = (img - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
         got = dst.float().cpu()
         assert got[..., 3:].abs().max() == 0
         assert rel_l2(nchw(got[..., :3]), ref) < (1e-6 if dt == torch.float32 else 3e-3)
     back = torch.empty(2, 3, 10, 14, device=cuda)
     d32 = torch.zeros(2, 10, 14, 4, device=cuda)
-    ops.nchw_to_nhwc(img.to(cuda), d32)
+    ops.nchw_to_nhwc(imgd, d32)
     ops.nhwc_to_nchw(ops.view(d32), back)
     assert torch.equal(back.cpu(), img)
     # maxpool (+ fused relu) forward / backward against ATen
@@ -248,7 +255,8 @@ def test_layout_and_pool(cuda):
     ops.maxpool2x2(ops.view(xd), ops.view(yd), 2, 12, 20, True)
     assert torch.equal(nchw(yd.cpu()), y.detach())
     gxd = torch.empty_like(xd)
-    ops.maxpool2x2_bwd(ops.view(xd), ops.view(nhwc(gy).to(cuda)), ops.view(gxd), 2, 12, 20, True)
+    gyd = nhwc(gy).to(cuda)
+    ops.maxpool2x2_bwd(ops.view(xd), ops.view(gyd), ops.view(gxd), 2, 12, 20, True)
     assert torch.equal(nchw(gxd.cpu()), xr.grad)
 
 
@@ -269,10 +277,11 @@ def test_pixel_loss(cuda, kind, numel_shape):
     ref.backward()
     out = torch.zeros(1, device=cuda)
     grad = torch.empty(numel_shape, device=cuda)
-    ops.pixel_loss(code, pred.detach().to(cuda), tgt.to(cuda), 0.7, out, grad=grad)
+    pd, td = pred.detach().to(cuda), tgt.to(cuda)
+    ops.pixel_loss(code, pd, td, 0.7, out, grad=grad)
     assert abs(out.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-9
     assert rel_l2(grad.cpu(), pred.grad) < 2e-6
-    ops.pixel_loss(code, pred.detach().to(cuda), tgt.to(cuda), 0.7, out, grad=grad, accumulate_loss=True, accumulate_grad=True)
+    ops.pixel_loss(code, pd, td, 0.7, out, grad=grad, accumulate_loss=True, accumulate_grad=True)
     assert abs(out.item() - 2 * ref.item()) <= 4e-6 * abs(ref.item()) + 1e-9
     assert rel_l2(grad.cpu(), 2 * pred.grad) < 2e-6
     # reference invariant (tests/test_losses/test_losses.py:114-128): black vs black is ~0
