@@ -65,7 +65,7 @@ size_t      tr_conv3x3_packed_bytes(int cin, int cout, int compute);
  * (what autograd's conv backward computes at sr_model.py:681).
  *
  *   v  = conv(in) + bias ; v = act(v)
- *   v  = v*scale1 + res1 ; v = v*scale2 + res2          (each only if resN.ptr != NULL)
+ *   v  = v*scale1 + res1_scale*res1 ; v = v*scale2 + res2_scale*res2   (each only if resN.ptr != NULL)
  *   v *= (mask > 0 ? 1 : mask_slope)                      (only if mask.ptr  != NULL)
  *   out = (out.dtype) v ; out2 = (out2.dtype)(v*out2_scale)   (out2 optional)
  *
@@ -82,6 +82,7 @@ typedef struct tr_conv3x3_desc {
     int32_t act;              /* TR_ACT_*                                                     */
     float   slope;            /* LeakyReLU negative slope                                     */
     float   scale1, scale2;
+    float   res1_scale, res2_scale;
     float   mask_slope;
     float   out2_scale;
     tr_view in, out, out2, res1, res2, mask;
@@ -146,8 +147,12 @@ int tr_nhwc_to_nchw(void* stream, tr_view src, float* dst, int n, int c_dst, int
 /* gradient of tr_nchw_to_nhwc wrt src: dst_nchw[c] = g[c] / std[c] */
 int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w,
                            const float* inv_std3, int accumulate);
-/* out = (out.dtype)(in * scale) for NHWC views of equal shape */
-int tr_scale_copy(void* stream, tr_view in, tr_view out, int64_t npix, float scale);
+/* out = (out.dtype)(a*sa + b*sb) for NHWC views of equal shape (b optional) -- residual adds of the
+ * gradient streams and dtype conversion */
+int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix);
+/* adjoint of nn.Upsample(scale_factor=2, mode="nearest") (scunet_aaf6aa_arch.py:371): 2x2 sum pooling,
+ * optionally times the LeakyReLU derivative taken from `mask` (the saved activation at low resolution) */
+int tr_sumpool2x2(void* stream, tr_view in, tr_view out, tr_view mask, float mask_slope, int n, int h_in, int w_in);
 /* 2x2/2 max pooling (torchvision VGG19 features 'M', perceptual_fp16_loss.py:12-50) with fused
  * preceding ReLU: out = maxpool(relu?(in)); backward routes to the first maximal element like ATen. */
 int tr_maxpool2x2(void* stream, tr_view in, tr_view out, int n, int h_in, int w_in, int relu_first);

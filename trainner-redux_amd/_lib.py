@@ -28,7 +28,8 @@ class Conv3x3Desc(C.Structure):
         ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
         ("cin", C.c_int32), ("cout", C.c_int32),
         ("compute", C.c_int32), ("in_mode", C.c_int32), ("pad_mode", C.c_int32), ("act", C.c_int32),
-        ("slope", C.c_float), ("scale1", C.c_float), ("scale2", C.c_float), ("mask_slope", C.c_float), ("out2_scale", C.c_float),
+        ("slope", C.c_float), ("scale1", C.c_float), ("scale2", C.c_float), ("res1_scale", C.c_float), ("res2_scale", C.c_float),
+        ("mask_slope", C.c_float), ("out2_scale", C.c_float),
         ("inp", View), ("out", View), ("out2", View), ("res1", View), ("res2", View), ("mask", View),
         ("wpacked", C.c_void_p), ("bias", C.c_void_p),
     ]
@@ -78,7 +79,8 @@ SYMBOLS = {
     "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_nhwc_to_nchw_scaled": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
-    "tr_scale_copy": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_float]),
+    "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64]),
+    "tr_sumpool2x2": (C.c_int, [C.c_void_p, View, View, View, C.c_float, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_pixel_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float,

@@ -34,7 +34,7 @@ struct ConvArgs {
     int up;            // 0/1: nearest x2 upsample fused into the load
     int replicate;
     int act;
-    float slope, scale1, scale2, mask_slope, out2_scale;
+    float slope, scale1, scale2, rs1, rs2, mask_slope, out2_scale;
     tr_view in, out, out2, res1, res2, mask;
     const char* wpacked;
     const float* bias;
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(ConvArgs a) {
                 if (full) {
                     if (a.res1.ptr) {
                         const float4 rr = tr::view_load4(a.res1, pix, co, a.vec_res1);
-                        v[0] = v[0] * a.scale1 + rr.x; v[1] = v[1] * a.scale1 + rr.y;
-                        v[2] = v[2] * a.scale1 + rr.z; v[3] = v[3] * a.scale1 + rr.w;
+                        v[0] = v[0] * a.scale1 + a.rs1 * rr.x; v[1] = v[1] * a.scale1 + a.rs1 * rr.y;
+                        v[2] = v[2] * a.scale1 + a.rs1 * rr.z; v[3] = v[3] * a.scale1 + a.rs1 * rr.w;
                     }
                     if (a.res2.ptr) {
                         const float4 rr = tr::view_load4(a.res2, pix, co, a.vec_res2);
-                        v[0] = v[0] * a.scale2 + rr.x; v[1] = v[1] * a.scale2 + rr.y;
-                        v[2] = v[2] * a.scale2 + rr.z; v[3] = v[3] * a.scale2 + rr.w;
+                        v[0] = v[0] * a.scale2 + a.rs2 * rr.x; v[1] = v[1] * a.scale2 + a.rs2 * rr.y;
+                        v[2] = v[2] * a.scale2 + a.rs2 * rr.z; v[3] = v[3] * a.scale2 + a.rs2 * rr.w;
                     }
                     if (a.mask.ptr) {
                         const float4 mm = tr::view_load4(a.mask, pix, co, a.vec_mask);
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(ConvArgs a) {
                 } else {
                     for (int i = 0; i < 4 && co + i < a.cout; ++i) {
                         float x = v[i];
-                        if (a.res1.ptr) x = x * a.scale1 + tr::view_load(a.res1, pix, co + i);
-                        if (a.res2.ptr) x = x * a.scale2 + tr::view_load(a.res2, pix, co + i);
+                        if (a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + i);
+                        if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + i);
                         if (a.mask.ptr) x *= tr::view_load(a.mask, pix, co + i) > 0.f ? 1.f : a.mask_slope;
                         tr::view_store(a.out, pix, co + i, x);
                         if (a.out2.ptr) tr::view_store(a.out2, pix, co + i, x * a.out2_scale);
@@ -271,7 +271,7 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     a.cin = d->cin; a.cout = d->cout;
     a.replicate = d->pad_mode == TR_PAD_REPLICATE;
     a.act = d->act; a.slope = d->slope;
-    a.scale1 = d->scale1; a.scale2 = d->scale2; a.mask_slope = d->mask_slope; a.out2_scale = d->out2_scale;
+    a.scale1 = d->scale1; a.scale2 = d->scale2; a.rs1 = d->res1_scale; a.rs2 = d->res2_scale; a.mask_slope = d->mask_slope; a.out2_scale = d->out2_scale;
     a.in = d->in; a.out = d->out; a.out2 = d->out2; a.res1 = d->res1; a.res2 = d->res2; a.mask = d->mask;
     a.wpacked = (const char*)d->wpacked; a.bias = d->bias;
     const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);

@@ -41,14 +41,44 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tr_view src, float* _
     }
 }
 
-__global__ __launch_bounds__(256) void scale_copy_kernel(tr_view in, tr_view out, int64_t npix, int c4, float scale, int vin, int vout) {
+__global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, int c4, int va,
+                                                     int vb, int vout) {
     const int64_t total = npix * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / c4;
         const int c = (int)(i - p * c4) * 4;
-        float4 v = tr::view_load4(in, p, c, vin);
-        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        float4 v = tr::view_load4(a, p, c, va);
+        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+        if (b.ptr) {
+            const float4 w = tr::view_load4(b, p, c, vb);
+            v.x += sb * w.x; v.y += sb * w.y; v.z += sb * w.z; v.w += sb * w.w;
+        }
         tr::view_store4(out, p, c, v, vout);
+    }
+}
+
+// one thread = one LOW-resolution pixel x 4 channels
+__global__ __launch_bounds__(256) void sumpool_kernel(tr_view in, tr_view out, tr_view mask, float mslope, int n, int hin, int win, int vin,
+                                                       int vout, int vmask) {
+    const int ho = hin >> 1, wo = win >> 1, c4 = out.c >> 2;
+    const int64_t total = (int64_t)n * ho * wo * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int c = (int)(t % c4) * 4; t /= c4;
+        const int x = (int)(t % wo); t /= wo;
+        const int y = (int)(t % ho);
+        const int nb = (int)(t / ho);
+        const int64_t p00 = ((int64_t)nb * hin + 2 * y) * win + 2 * x;
+        const float4 a = tr::view_load4(in, p00, c, vin), b = tr::view_load4(in, p00 + 1, c, vin);
+        const float4 d = tr::view_load4(in, p00 + win, c, vin), e = tr::view_load4(in, p00 + win + 1, c, vin);
+        float4 s = make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+        const int64_t po = ((int64_t)nb * ho + y) * wo + x;
+        if (mask.ptr) {
+            const float4 m = tr::view_load4(mask, po, c, vmask);
+            s.x *= m.x > 0.f ? 1.f : mslope; s.y *= m.y > 0.f ? 1.f : mslope;
+            s.z *= m.z > 0.f ? 1.f : mslope; s.w *= m.w > 0.f ? 1.f : mslope;
+        }
+        tr::view_store4(out, po, c, s, vout);
     }
 }
 
@@ -148,12 +178,22 @@ extern "C" int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int
     return tr::launch_status("tr_nhwc_to_nchw_scaled");
 }
 
-extern "C" int tr_scale_copy(void* stream, tr_view in, tr_view out, int64_t npix, float scale) {
-    TR_REQUIRE(in.ptr && out.ptr && npix > 0 && in.c == out.c && in.c % 4 == 0, TR_EINVAL,
-               "tr_scale_copy: views must have equal channel counts that are multiples of 4");
-    hipLaunchKernelGGL(scale_copy_kernel, dim3(grid_for(npix * (in.c / 4))), dim3(256), 0, (hipStream_t)stream, in, out, npix, in.c / 4,
-                       scale, (int)tr::view_vec4_ok(in), (int)tr::view_vec4_ok(out));
-    return tr::launch_status("tr_scale_copy");
+extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix) {
+    TR_REQUIRE(a.ptr && out.ptr && npix > 0 && a.c == out.c && a.c % 4 == 0 && (!b.ptr || b.c == a.c), TR_EINVAL,
+               "tr_axpby: views must have equal channel counts that are multiples of 4");
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (a.c / 4))), dim3(256), 0, (hipStream_t)stream, a, sa, b, sb, out, npix, a.c / 4,
+                       (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out));
+    return tr::launch_status("tr_axpby");
+}
+
+extern "C" int tr_sumpool2x2(void* stream, tr_view in, tr_view out, tr_view mask, float mask_slope, int n, int h_in, int w_in) {
+    TR_REQUIRE(in.ptr && out.ptr && n > 0 && in.c == out.c && in.c % 4 == 0 && (!mask.ptr || mask.c == in.c), TR_EINVAL,
+               "tr_sumpool2x2: channel mismatch");
+    TR_REQUIRE(h_in % 2 == 0 && w_in % 2 == 0 && h_in > 0 && w_in > 0, TR_EUNSUPPORTED, "tr_sumpool2x2: odd spatial dims %dx%d", h_in, w_in);
+    const int64_t work = (int64_t)n * (h_in / 2) * (w_in / 2) * (in.c / 4);
+    hipLaunchKernelGGL(sumpool_kernel, dim3(grid_for(work)), dim3(256), 0, (hipStream_t)stream, in, out, mask, mask_slope, n, h_in, w_in,
+                       (int)tr::view_vec4_ok(in), (int)tr::view_vec4_ok(out), (int)tr::view_vec4_ok(mask));
+    return tr::launch_status("tr_sumpool2x2");
 }
 
 extern "C" int tr_maxpool2x2(void* stream, tr_view in, tr_view out, int n, int h_in, int w_in, int relu_first) {

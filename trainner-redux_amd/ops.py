@@ -58,11 +58,12 @@ def packed_bytes(cin: int, cout: int, compute: int) -> int:
 
 def conv3x3(*, n, h, w, cin, cout, compute, inp: L.View, out: L.View, wpacked: torch.Tensor, bias: torch.Tensor | None = None,
             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, act=L.ACT_NONE, slope=0.2, res1: L.View = NULL_VIEW, scale1=1.0,
-            res2: L.View = NULL_VIEW, scale2=1.0, mask: L.View = NULL_VIEW, mask_slope=0.2, out2: L.View = NULL_VIEW, out2_scale=1.0):
+            res2: L.View = NULL_VIEW, scale2=1.0, res1_scale=1.0, res2_scale=1.0, mask: L.View = NULL_VIEW, mask_slope=0.2, out2: L.View = NULL_VIEW, out2_scale=1.0):
     d = L.Conv3x3Desc()
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.compute, d.in_mode, d.pad_mode, d.act = compute, in_mode, pad_mode, act
     d.slope, d.scale1, d.scale2, d.mask_slope, d.out2_scale = slope, scale1, scale2, mask_slope, out2_scale
+    d.res1_scale, d.res2_scale = res1_scale, res2_scale
     d.inp, d.out, d.out2, d.res1, d.res2, d.mask = inp, out, out2, res1, res2, mask
     d.wpacked = wpacked.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -152,8 +153,12 @@ def nhwc_to_nchw_scaled(src_view: L.View, dst: torch.Tensor, inv_std, accumulate
             "tr_nhwc_to_nchw_scaled")
 
 
-def scale_copy(inp: L.View, out: L.View, npix: int, scale: float):
-    L.check(L.lib().tr_scale_copy(stream_ptr(), inp, out, npix, scale), "tr_scale_copy")
+def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int):
+    L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix), "tr_axpby")
+
+
+def sumpool2x2(inp: L.View, out: L.View, mask: L.View, mask_slope: float, n, h_in, w_in):
+    L.check(L.lib().tr_sumpool2x2(stream_ptr(), inp, out, mask, mask_slope, n, h_in, w_in), "tr_sumpool2x2")
 
 
 def maxpool2x2(inp: L.View, out: L.View, n, h_in, w_in, relu_first: bool):
