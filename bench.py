@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: training images/sec of `SRModel.optimize_parameters` on synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload at N = 1 (BASELINE.json configs[1]): ESRGAN 4x (RRDBNet 23 blocks), L1 + perceptual (VGG19, `perceptualloss`
+= fp32), bf16 compute, 256x256 -> 1024x1024 tiles, batch 16 per GPU, AdamW + EMA, every step applies the gradient.
+A "step" = one full `optimize_parameters` call on one resident batch; value = global images / max-over-ranks time.
+Weak scaling: per-GPU batch is fixed; gradients are exchanged with ONE RCCL all-reduce of the flat gradient arena.
+
+The JSON line also carries
+  roofline     -- dominant kernel (the bf16 MFMA 3x3 conv): algorithmic FLOPs per launch / its average launch
+                  duration, measured live with HIP events on the launch stream during the timed region;
+  cpu_baseline -- the oracle's step (pure PyTorch fp32, the reference's CPU path) timed on this host on a bounded
+                  sample and scaled to the same unit.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--lq", type=int, default=256, help="LR tile size")
+    ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_opt(args):
+    from trainner_redux_amd.utils.options import parse_options_dict
+
+    losses = [dict(type="l1loss", loss_weight=1.0)]
+    if args.losses == "l1+perceptual":
+        losses.append(dict(type="perceptualloss", loss_weight=0.01, criterion="charbonnier"))
+    elif args.losses == "l1+perceptualfp16":
+        losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
+    return parse_options_dict(dict(
+        name="bench", scale=4, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute == "bf16", amp_bf16=True,
+        network_g=dict(type="esrgan", num_blocks=args.blocks),
+        datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
+        train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
+                   optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
+                   scheduler=dict(type="MultiStepLR", milestones=[500000], gamma=0.5), losses=losses),
+    ))
+
+
+class ConvTimer:
+    """HIP events around every tr_conv3x3 launch (recorded on the launch stream = torch's current stream)."""
+
+    def __init__(self):
+        self.records = []   # (key, flops, ev0, ev1)
+        self.enabled = False
+
+    def install(self):
+        from trainner_redux_amd import _lib as L, ops
+
+        orig = ops.conv3x3
+        timer = self
+
+        def timed(**kw):
+            if not timer.enabled:
+                return orig(**kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(**kw)
+            e1.record()
+            cd = "bf16" if kw["compute"] == L.BF16 else "f32"
+            flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * 9 * kw["cin"] * kw["cout"]
+            timer.records.append(((cd, 64 if kw["cout"] > 32 else 32), flops, e0, e1))
+
+        ops.conv3x3 = timed
+        import trainner_redux_amd.archs.rrdbnet_arch as ra
+
+        ra.ops = ops  # same module object; attribute lookups go through ops.conv3x3
+
+    def summary(self):
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += flops
+            a[2] += ms
+        return agg
+
+
+def host_threads() -> int:
+    """CPU share of this process: affinity mask, cgroup quota, capped at 16 (the GPU box's share for one GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(args, perceptual: bool):
+    """Oracle step on the host cores: 1 image, 64 -> 256 tile = 1/16 of the pixels of one 256 -> 1024 image."""
+    from collections import OrderedDict
+
+    from oracle import esrgan as OE, losses as OL, step as OS, vgg as OV
+
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    hp = OE.esrgan_hparams(scale=4, num_blocks=args.blocks)
+    sd = OE.init_state_dict(hp, 0)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    st = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    ema = OS.EMAState(OrderedDict((k, v.data) for k, v in params.items()), beta=0.999, power=0.75)
+    g = torch.Generator().manual_seed(1024)
+    s_lq = 64
+    gt = torch.rand(1, 3, 4 * s_lq, 4 * s_lq, generator=g)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    fns = OrderedDict(l_g_l1=(OL.l1, 1.0))
+    if perceptual:
+        vsd = OV.synthetic_state_dict(0)
+        fns["l_g_perceptual"] = (lambda o, t: OV.perceptual_loss(vsd, o, t), 0.01)
+    fwd = lambda p, x: OE.forward(p, x, hp)  # noqa: E731
+    OS.generator_step(params, fwd, fns, lq, gt, st, ema)  # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or time.perf_counter() - t0 < 10.0:
+        OS.generator_step(params, fwd, fns, lq, gt, st, ema)
+        reps += 1
+        if time.perf_counter() - t0 > 40.0:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    scale = (args.lq / s_lq) ** 2
+    return dict(value=1.0 / (dt * scale), unit="images/sec", cores=threads, kind="port",
+                sample=f"{reps} oracle steps of batch 1 at {s_lq}->{4 * s_lq} ({dt:.2f} s each, fp32, {threads} threads); "
+                       f"one {args.lq}->{4 * args.lq} image = {scale:.0f}x those pixels, value scaled by 1/{scale:.0f}")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "bench.py needs an MI355X; this package has no CPU execution path"}))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local_rank)
+
+    import trainner_redux_amd  # noqa: F401
+    from trainner_redux_amd.models import build_model
+    from trainner_redux_amd.utils.misc import set_random_seed
+
+    opt = make_opt(args)
+    set_random_seed(1024)   # same weights on every replica (DDP broadcasts rank 0's, base_model.py:228-234)
+    model = build_model(opt)
+    if world > 1:
+        p, _ = model.net_g.flat_parameters()
+        dist.broadcast(p, 0)
+    torch.manual_seed(1024 + rank)
+    n, s = args.batch, args.lq
+    gt = torch.rand(n, 3, 4 * s, 4 * s, device=dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    batch = {"lq": lq, "gt": gt}
+    timer = ConvTimer()
+    if not args.no_roofline:
+        timer.install()
+
+    def step(i):
+        model.feed_data(batch)
+        model.optimize_parameters(i, 0, True)
+        model.update_learning_rate(i, -1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"model built; warm-up {args.warmup} steps")
+    it = 0
+    for _ in range(args.warmup):
+        it += 1
+        step(it)
+    fence()
+    log(f"warm-up done; timing {args.steps} steps")
+    timer.enabled = not args.no_roofline
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        it += 1
+        step(it)
+    fence()
+    dt = time.perf_counter() - t0
+    log(f"timed region {dt:.3f} s")
+    timer.enabled = False
+    stats = model.get_current_log()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            "metric": "training images/sec (256->1024 4x SR) ESRGAN",
+            "value": n * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"ESRGAN 4x (RRDBNet {args.blocks} blocks) {args.losses} {args.compute}, {s}->{4 * s} tiles, "
+                                   f"batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+                       "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
+                       "l_g_total": stats.get("l_g_total")},
+        }
+        if not args.no_roofline and timer.records:
+            agg = timer.summary()
+            key = max(agg, key=lambda k: agg[k][2])
+            cnt, flops, msum = agg[key]
+            peak = 2500.0 if key[0] == "bf16" else 157.3
+            ach = flops / (msum * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel<{key[0]}, cout-group {key[1]}>", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": cnt, "avg_launch_ms": msum / cnt,
+                               "share_of_step": msum / (dt * 1e3),
+                               "all": {f"{k[0]}/cg{k[1]}": {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
+        if not args.no_cpu_baseline and world == 1:
+            log(f"cpu baseline on {host_threads()} threads")
+            out["cpu_baseline"] = cpu_baseline(args, "perceptual" in args.losses)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -160,15 +160,34 @@ int tr_maxpool2x2_bwd(void* stream, tr_view in, tr_view gout, tr_view gin, int n
                       int relu_first);
 
 /* ---- pixel-loss heads -------------------------------------------------------------------------
- * l1 / mse / charbonnier with reduction 'mean' (basic_loss.py:16-28, loss_util.py:8-59):
- *   loss_out[0] (+)= weight * mean(elem(pred - target)) ;  grad = weight * d elem / d pred / numel
- * Works on flat fp32 or bf16 arrays (NCHW image batches and NHWC feature maps alike).  One pass
- * reads pred and target once and writes grad once; the scalar is reduced without float atomics
- * (fixed-order two-level sum) so it is bitwise reproducible.  grad may be NULL (forward only).
+ * l1 / mse / charbonnier with reduction 'mean' (basic_loss.py:16-28, loss_util.py:8-59) over flat fp32 or
+ * bf16 arrays (NCHW image batches and NHWC feature maps alike), fused with the bookkeeping of
+ * sr_model.py:639-663 so that one pass serves the logged value, the running total and the gradient:
+ *   m = mean(elem(pred - target))
+ *   value_out[0]  = value_weight * m                      (the weighted loss that is logged)
+ *   total_out[0] += total_weight * m                      (l_g_total; optional)
+ *   grad        (+)= grad_weight * d m / d pred           (optional; accumulate_grad selects += vs =)
+ * pred and target are read once, grad written once; the scalar is reduced without float atomics
+ * (fixed-order two-level sum) so it is bitwise reproducible.
  */
-int tr_pixel_loss(void* stream, int kind, const void* pred, const void* target, int dtype,
-                  int64_t numel, float weight, float eps, float* loss_out, int accumulate_loss,
-                  void* grad, int grad_dtype, int accumulate_grad, float* partials /* >= 1024 floats */);
+typedef struct tr_pixel_loss_desc {
+    int32_t kind;             /* TR_LOSS_*                                   */
+    int32_t dtype;            /* dtype of pred and target                    */
+    int32_t grad_dtype;
+    int32_t accumulate_grad;
+    const void* pred;
+    const void* target;
+    int64_t numel;
+    float   eps;              /* charbonnier                                 */
+    float   value_weight;
+    float   total_weight;
+    float   grad_weight;
+    float*  value_out;        /* 1 float                                     */
+    float*  total_out;        /* 1 float or NULL                             */
+    void*   grad;             /* numel elements of grad_dtype or NULL        */
+    float*  partials;         /* >= 1024 floats of scratch                   */
+} tr_pixel_loss_desc;
+int tr_pixel_loss(void* stream, const tr_pixel_loss_desc* d);
 
 /* ---- optimizer sweep --------------------------------------------------------------------------
  * torch.optim.AdamW (optimizers/__init__.py:30-47, templates: lr 2e-4, betas (0.9, 0.99), wd 0)

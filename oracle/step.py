@@ -16,7 +16,7 @@ Optimizer: torch.optim.AdamW semantics (lr, betas, eps 1e-8, decoupled weight de
 reference's registered `AdamW` (/root/reference/traiNNer/optimizers/__init__.py:30-47).
 EMA: ema-pytorch (absent from this container; formula restated from its published source, values
 *parity unpinned*): step counter starts at 0; update(): s = step; step += 1; if s <= update_after_step:
-copy params; else decay = clamp(1 - (1 + (step - update_after_step - 1))**(-power), 0, beta),
+copy params; on the first later update copy once more (`initted`), then decay = clamp(1 - (1 + (step - update_after_step - 1))**(-power), 0, beta),
 ema = lerp(ema, p, 1 - decay).  ctor kwargs at sr_model.py:226-235.
 """
 from __future__ import annotations
@@ -69,9 +69,9 @@ class EMAState:
         if s <= self.uas or not self.initted:
             for k, v in params.items():
                 self.shadow[k].copy_(v)
-            self.initted = True
             if s <= self.uas:
                 return
+            self.initted = True
         d = self.current_decay()
         for k, v in params.items():
             self.shadow[k].lerp_(v, 1 - d)

@@ -72,7 +72,7 @@ def test_esrgan_fp32_forward_backward(cuda, cfg):
     loss = torch.zeros(1, device=cuda)
     gout = torch.empty_like(out)
     gtd = gt.to(cuda)
-    ops.pixel_loss(L.LOSS_L1, out, gtd, 1.0, loss, grad=gout)
+    ops.pixel_loss(L.LOSS_L1, out, gtd, loss, grad=gout)
     assert abs(loss.item() - ref_loss.item()) < 1e-5 * ref_loss.item()
     # sign(out - gt) may differ where |out - gt| ~ 1e-7: the backward operator is compared on the oracle's d(loss)/d(out)
     assert (gout.cpu() != ref_gout).float().mean() < 1e-4
@@ -105,7 +105,7 @@ def test_esrgan_bf16_forward_backward(cuda, cfg):
     loss = torch.zeros(1, device=cuda)
     gout = torch.empty_like(out)
     gtd = gt.to(cuda)
-    ops.pixel_loss(L.LOSS_L1, out, gtd, 1.0, loss, grad=gout)
+    ops.pixel_loss(L.LOSS_L1, out, gtd, loss, grad=gout)
     e_loss = abs(loss.item() - ref_loss.item()) / ref_loss.item()
     assert e_loss < 1e-3, e_loss
     print(f"loss {loss.item():.6f} | bf16-policy oracle {ref_loss.item():.6f} (rel {e_loss:.1e}) | fp32 reference {loss32.item():.6f} "

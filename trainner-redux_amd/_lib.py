@@ -57,6 +57,15 @@ class Wgrad3x3Desc(C.Structure):
     ]
 
 
+class PixelLossDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("dtype", C.c_int32), ("grad_dtype", C.c_int32), ("accumulate_grad", C.c_int32),
+        ("pred", C.c_void_p), ("target", C.c_void_p), ("numel", C.c_int64),
+        ("eps", C.c_float), ("value_weight", C.c_float), ("total_weight", C.c_float), ("grad_weight", C.c_float),
+        ("value_out", C.c_void_p), ("total_out", C.c_void_p), ("grad", C.c_void_p), ("partials", C.c_void_p),
+    ]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [
         ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
@@ -83,8 +92,7 @@ SYMBOLS = {
     "tr_sumpool2x2": (C.c_int, [C.c_void_p, View, View, View, C.c_float, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "tr_pixel_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_float,
-                                C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tr_pixel_loss": (C.c_int, [C.c_void_p, C.POINTER(PixelLossDesc)]),
     "tr_sumsq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tr_adamw_ema": (C.c_int, [C.c_void_p, C.POINTER(AdamWDesc)]),
 }

@@ -129,10 +129,23 @@ class RRDBNet(nn.Module):
             if p.grad is not None:
                 garena[o:o + p.numel()].copy_(p.grad.reshape(-1))
             p.data = arena[o:o + p.numel()].view(p.shape)
-            p.grad = garena[o:o + p.numel()].view(p.shape)
+            p.grad = garena[o:o + p.numel()].view(p.shape) if p.requires_grad else None
         self._arena, self._grad_arena, self._offsets = arena, garena, offs
         self._plan = None
         self._ws = {}
+
+    def __deepcopy__(self, memo):
+        # an EMA twin must not inherit workspaces, saved activations or slabs that alias the online net
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy as _copy
+        for k, v in self.__dict__.items():
+            if k in ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets"):
+                continue
+            new.__dict__[k] = _copy.deepcopy(v, memo)
+        new._ws, new._saved, new._plan, new._trigger, new._arena, new._grad_arena = {}, None, None, None, None, None
+        return new
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -143,7 +156,7 @@ class RRDBNet(nn.Module):
         ps = list(self.parameters())
         if self._arena is None or ps[0].data_ptr() != self._arena.data_ptr() or ps[0].device != self._arena.device:
             self._flatten()
-        elif ps[0].grad is None or ps[-1].grad is None or ps[0].grad.data_ptr() != self._grad_arena.data_ptr():
+        elif ps[0].requires_grad and (ps[0].grad is None or ps[-1].grad is None or ps[0].grad.data_ptr() != self._grad_arena.data_ptr()):
             # optimizer.zero_grad(set_to_none=True) dropped the views: re-attach, zeroed
             self._grad_arena.zero_()
             for p, o in zip(ps, self._offsets):

@@ -96,15 +96,15 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const void* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = bs;
 }
 
-__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ partials, int nparts, float scale, float* out, int acc,
-                                                     int take_sqrt) {
+__global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ partials, int nparts, float scale, float* out,
+                                                     float scale2, float* out2, int take_sqrt) {
     __shared__ float sh[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += partials[i];
     const float t = block_sum(s, sh);
     if (threadIdx.x == 0) {
-        float r = take_sqrt ? sqrtf(t) : t * scale;
-        out[0] = acc ? out[0] + r : r;
+        out[0] = take_sqrt ? sqrtf(t) : t * scale;
+        if (out2) out2[0] += t * scale2;
     }
 }
 
@@ -131,31 +131,28 @@ inline int blocks_for(int64_t numel) {
 
 }  // namespace
 
-extern "C" int tr_pixel_loss(void* stream, int kind, const void* pred, const void* target, int dtype, int64_t numel, float weight,
-                             float eps, float* loss_out, int accumulate_loss, void* grad, int grad_dtype, int accumulate_grad,
-                             float* partials) {
-    TR_REQUIRE(pred && target && loss_out && partials && numel > 0, TR_EINVAL, "tr_pixel_loss: bad arguments");
-    TR_REQUIRE(kind >= TR_LOSS_L1 && kind <= TR_LOSS_CHARBONNIER, TR_EINVAL, "tr_pixel_loss: unknown kind %d", kind);
-    TR_REQUIRE(((uintptr_t)pred) % 16 == 0 && ((uintptr_t)target) % 16 == 0, TR_EALIGN, "tr_pixel_loss: pred/target must be 16-byte aligned");
+extern "C" int tr_pixel_loss(void* stream, const tr_pixel_loss_desc* d) {
+    TR_REQUIRE(d && d->pred && d->target && d->value_out && d->partials && d->numel > 0, TR_EINVAL, "tr_pixel_loss: bad arguments");
+    TR_REQUIRE(d->kind >= TR_LOSS_L1 && d->kind <= TR_LOSS_CHARBONNIER, TR_EINVAL, "tr_pixel_loss: unknown kind %d", d->kind);
+    TR_REQUIRE(((uintptr_t)d->pred) % 16 == 0 && ((uintptr_t)d->target) % 16 == 0, TR_EALIGN,
+               "tr_pixel_loss: pred/target must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    const int nb = blocks_for(numel);
-    const float gscale = weight / (float)numel;
-    switch (kind) {
-        case TR_LOSS_L1:
-            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_L1>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps, grad,
-                               grad_dtype, accumulate_grad, partials);
-            break;
-        case TR_LOSS_MSE:
-            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_MSE>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps, grad,
-                               grad_dtype, accumulate_grad, partials);
-            break;
-        default:
-            hipLaunchKernelGGL(pixel_loss_kernel<TR_LOSS_CHARBONNIER>, dim3(nb), dim3(256), 0, st, pred, target, dtype, numel, gscale, eps,
-                               grad, grad_dtype, accumulate_grad, partials);
+    const int nb = blocks_for(d->numel);
+    const float inv = 1.f / (float)d->numel;
+    const float gscale = d->grad_weight * inv;
+#define TR_LAUNCH_LOSS(K)                                                                                                          \
+    hipLaunchKernelGGL(pixel_loss_kernel<K>, dim3(nb), dim3(256), 0, st, d->pred, d->target, d->dtype, d->numel, gscale, d->eps, d->grad, \
+                       d->grad_dtype, d->accumulate_grad, d->partials)
+    switch (d->kind) {
+        case TR_LOSS_L1: TR_LAUNCH_LOSS(TR_LOSS_L1); break;
+        case TR_LOSS_MSE: TR_LAUNCH_LOSS(TR_LOSS_MSE); break;
+        default: TR_LAUNCH_LOSS(TR_LOSS_CHARBONNIER);
     }
+#undef TR_LAUNCH_LOSS
     int rc = tr::launch_status("tr_pixel_loss");
     if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, weight / (float)numel, loss_out, accumulate_loss, 0);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, d->partials, nb, d->value_weight * inv, d->value_out,
+                       d->total_weight * inv, d->total_out, 0);
     return tr::launch_status("tr_pixel_loss(finish)");
 }
 
@@ -167,6 +164,6 @@ extern "C" int tr_sumsq(void* stream, const float* x, int64_t numel, float* norm
     hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, x, numel, partials);
     int rc = tr::launch_status("tr_sumsq");
     if (rc) return rc;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, 1.f, norm_out, 0, 1);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, partials, nb, 1.f, norm_out, 0.f, (float*)nullptr, 1);
     return tr::launch_status("tr_sumsq(finish)");
 }

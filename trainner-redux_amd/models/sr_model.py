@@ -1,0 +1,446 @@
+"""`SRModel`: the trainer object whose `optimize_parameters` is the hot path.
+
+Surface and step semantics follow /root/reference/traiNNer/models/sr_model.py (ctor :42-176, training setup :178-432,
+`feed_data` :434-450, `optimize_parameters` :452-828) and base_model.py (`get_current_log` :186-200, `reduce_loss_dict`
+:847-870, LR schedule :258-313,369-390).  What is different is *how* a step runs on MI355X:
+
+  * no autograd graph for the generator: `net_g.forward_hip` -> loss heads write d(loss)/d(output) into one buffer
+    (HIP heads fused with their reduction; foreign `nn.Module` losses through a one-node autograd on the output) ->
+    `net_g.backward_hip` accumulates into the flat gradient arena;
+  * data parallelism = one process per GPU, ONE RCCL all-reduce of the gradient arena (no DDP wrapper, no DataParallel);
+  * grad-norm, clipping, AdamW, EMA and zero_grad are one fused sweep; loss scalars stay on the device and are read
+    back only by `get_current_log()` (the reference syncs twice per step, :665 and :678);
+  * the reference's host-side quirks that change numbers are kept: dict-valued losses are multiplied by `accum_iters`
+    (:654-659), scalar ones divided (:661-663); the D loss is scaled by the G-side `loss_weight` (:763-768).
+The NaN/Inf check of :665 is evaluated on the host at log time (same RuntimeError text) instead of every step.
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from typing import Any
+
+import torch
+from torch import Tensor, nn
+
+from .. import ops
+from ..archs import build_network
+from ..losses import build_loss
+from ..optimizers import AdamW, build_optimizer
+from ..utils.dist_util import allreduce_flat_, get_dist_info
+from ..utils.misc import loss_type_to_label
+from .ema import EMA
+
+ARCHS_WITHOUT_FP16_PREFIXES = ("swinir",)  # arch_info.py:48-50 (all swinir_* are bf16-only)
+
+
+class SRModel:
+    def __init__(self, opt) -> None:
+        self.opt = opt
+        self.is_train = bool(opt.is_train)
+        if not torch.cuda.is_available() or opt.num_gpu == 0:
+            raise RuntimeError("SRModel (HIP) needs an MI355X: this package has no CPU execution path")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.use_amp = bool(opt.use_amp)
+        self.amp_bf16 = bool(opt.amp_bf16)
+        if self.use_amp and not self.amp_bf16:
+            raise NotImplementedError("fp16 AMP (GradScaler path) is not built yet on the HIP path: set amp_bf16: true")
+        self.compute_dtype = torch.bfloat16 if self.use_amp else torch.float32
+        self.amp_dtype = self.compute_dtype
+        self.schedulers: list = []
+        self.optimizers: list = []
+        self.optimizers_skipped: list[bool] = []
+        self.log_dict: dict[str, Any] = {}
+        self.loss_samples = 0
+        self.lq: Tensor | None = None
+        self.gt: Tensor | None = None
+        self.output: Tensor | None = None
+        self.with_metrics = False
+        self.metric_results: dict = {}
+        self.training_automation_manager = None
+        self.batch_augment = None
+        self.dynamic_loss_scheduler = None
+
+        assert opt.network_g is not None, "network_g must be defined"
+        self.net_g = build_network({**opt.network_g, "scale": opt.scale}).to(self.device)
+        if hasattr(self.net_g, "compute_dtype"):
+            self.net_g.compute_dtype = self.compute_dtype
+        self.net_d: nn.Module | None = None
+        self.net_g_ema: EMA | None = None
+        self.losses: "OrderedDict[str, nn.Module]" = OrderedDict()
+        self.optimizer_g = None
+        self.optimizer_d = None
+        self.has_gan = False
+        self.accum_iters = 1
+        self.grad_clip = False
+        self.ema_decay = 0
+        if opt.path.pretrain_network_g is not None:
+            self.load_network(self.net_g, opt.path.pretrain_network_g, opt.path.strict_load_g, opt.path.param_key_g)
+        if self.is_train:
+            self._detect_gan()
+            self.init_training_settings()
+
+    # ------------------------------------------------------------------ setup ------------------------------
+    def _detect_gan(self) -> None:
+        train_opt = self.opt.train
+        for loss in (train_opt.losses or []):
+            if loss_type_to_label(loss["type"]) in ("l_g_gan", "l_g_featurematching") and float(loss.get("loss_weight", 0)) != 0:
+                self.has_gan = True
+        if train_opt.gan_opt is not None and float(train_opt.gan_opt.get("loss_weight", 0)) != 0:
+            self.has_gan = True
+        if self.has_gan:
+            if train_opt.optim_d is None:
+                raise ValueError("GAN loss requires discriminator optimizer (optim_d)")   # sr_model.py:147-154
+            if self.opt.network_d is None:
+                raise ValueError("GAN loss requires discriminator network (network_d)")
+            self.net_d = build_network(self.opt.network_d).to(self.device)
+            if self.opt.path.pretrain_network_d is not None:
+                self.load_network(self.net_d, self.opt.path.pretrain_network_d, self.opt.path.strict_load_d, self.opt.path.param_key_d)
+
+    def init_training_settings(self) -> None:
+        train_opt = self.opt.train
+        assert train_opt is not None
+        self.net_g.train()
+        if self.net_d is not None:
+            self.net_d.train()
+        ds = self.opt.datasets.get("train")
+        self.accum_iters = ds.accum_iter if ds is not None else 1
+        self.ema_decay = train_opt.ema_decay
+        if self.ema_decay > 0:
+            init_ema = None
+            if self.opt.path.pretrain_network_g_ema is not None:
+                init_ema = build_network({**self.opt.network_g, "scale": self.opt.scale}).to(self.device)
+                self.load_network(init_ema, self.opt.path.pretrain_network_g_ema, self.opt.path.strict_load_g, "params_ema")
+            switch_iter = train_opt.ema_switch_iter or None
+            self.net_g_ema = EMA(self.net_g, ema_model=init_ema, beta=self.ema_decay, allow_different_devices=True,
+                                 update_after_step=train_opt.ema_update_after_step, update_every=1, power=train_opt.ema_power,
+                                 update_model_with_ema_every=switch_iter).to(self.device)
+            self.net_g_ema.step = self.net_g_ema.step.cpu()
+            self.net_g_ema.initted = self.net_g_ema.initted.cpu()
+            if hasattr(self.net_g_ema.ema_model, "compute_dtype"):
+                self.net_g_ema.ema_model.compute_dtype = self.compute_dtype
+        self.grad_clip = train_opt.grad_clip
+        self.grad_clip_threshold = 1.0   # get_automation_clipping_threshold() default without automations
+        if train_opt.losses is None:
+            train_opt.losses = [getattr(train_opt, k) for k in train_opt.legacy_loss_opts if getattr(train_opt, k) is not None]
+        for loss in train_opt.losses:
+            assert "type" in loss, "all losses must define type"
+            assert "loss_weight" in loss, f"{loss['type']} must define loss_weight"
+            if float(loss["loss_weight"]) != 0:
+                label = loss_type_to_label(loss["type"])
+                self.losses[label] = build_loss(loss).to(self.device)
+        assert self.losses, "At least one loss must be defined."
+        self.setup_optimizers()
+        self.setup_schedulers()
+        dev = self.device
+        self._scal = torch.zeros(64, dtype=torch.float32, device=dev)   # device-resident loss scalars
+        self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._pending: list = []
+
+    def setup_optimizers(self) -> None:
+        train_opt = self.opt.train
+        assert train_opt.optim_g is not None
+        params = [p for p in self.net_g.parameters() if p.requires_grad]
+        if hasattr(self.net_g, "flat_parameters"):
+            self.net_g.flat_parameters()
+            params = [p for p in self.net_g.parameters() if p.requires_grad]
+        self.optimizer_g = build_optimizer(params, train_opt.optim_g)
+        self.optimizers.append(self.optimizer_g)
+        self.optimizers_skipped.append(False)
+        if self.net_d is not None and train_opt.optim_d is not None:
+            self.optimizer_d = build_optimizer(list(self.net_d.parameters()), train_opt.optim_d)
+            self.optimizers.append(self.optimizer_d)
+            self.optimizers_skipped.append(False)
+
+    def setup_schedulers(self) -> None:
+        sch = self.opt.train.scheduler
+        if sch is None:
+            return
+        sch = dict(sch)
+        kind = sch.pop("type")
+        for o in self.optimizers:
+            if kind in ("MultiStepLR", "MultiStepRestartLR"):
+                self.schedulers.append(torch.optim.lr_scheduler.MultiStepLR(o, milestones=sch["milestones"], gamma=sch.get("gamma", 0.1)))
+            elif kind == "CosineAnnealingLR":
+                self.schedulers.append(torch.optim.lr_scheduler.CosineAnnealingLR(o, **sch))
+            elif kind == "ConstantLR":
+                self.schedulers.append(torch.optim.lr_scheduler.ConstantLR(o, **sch))
+            else:
+                raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
+        self._init_lr = [[g["lr"] for g in o.param_groups] for o in self.optimizers]
+
+    # ------------------------------------------------------------------ loop surface -------------------------
+    def feed_data(self, data: dict) -> None:
+        assert "lq" in data
+        self.lq = data["lq"].to(self.device, non_blocking=True)
+        if "gt" in data:
+            self.gt = data["gt"].to(self.device, non_blocking=True)
+
+    def get_bare_model(self, net):
+        return net
+
+    def get_current_learning_rate(self) -> list[float]:
+        return [g["lr"] for g in self.optimizers[0].param_groups]
+
+    def update_learning_rate(self, current_iter: int, warmup_iter: int = -1) -> None:
+        # base_model.py:369-390: schedulers advance unless that optimizer's step was skipped; linear warm-up
+        if current_iter > 1:
+            for i, s in enumerate(self.schedulers):
+                if not (self.use_amp and self.optimizers_skipped[i]):
+                    s.step()
+        if current_iter < warmup_iter and self.schedulers:
+            for o, init in zip(self.optimizers, self._init_lr):
+                for g, lr0 in zip(o.param_groups, init):
+                    g["lr"] = lr0 / warmup_iter * current_iter
+
+    def reset_current_log(self) -> None:
+        self.log_dict = {}
+        self.loss_samples = 0
+
+    def _flush_pending(self) -> None:
+        """Fold device-resident scalars of finished steps into log_dict (one D2H copy per call)."""
+        if not self._pending:
+            return
+        torch.cuda.current_stream().synchronize()
+        for keys, vals, n in self._pending:
+            host = vals.tolist()
+            for k, v in zip(keys, host):
+                if k == "l_g_total" and not (v == v and abs(v) != float("inf")):
+                    self._pending = []
+                    raise RuntimeError("Training failed: NaN/Inf found in loss.")
+                self.log_dict[k] = self.log_dict.get(k, 0.0) + v * n
+        self._pending = []
+
+    def get_current_log(self) -> dict[str, float]:
+        self._flush_pending()
+        out = {}
+        for k, v in self.log_dict.items():
+            out[k] = (float(v) / self.loss_samples) if self.loss_samples > 0 else float(v)
+        rank, world = get_dist_info()
+        if world > 1:  # base_model.py:847-870 (mean over ranks), done at log time instead of every step
+            keys = sorted(out)
+            t = torch.tensor([out[k] for k in keys], dtype=torch.float32, device=self.device)
+            torch.distributed.all_reduce(t)
+            out = {k: float(v) / world for k, v in zip(keys, t.tolist())}
+        return out
+
+    # ------------------------------------------------------------------ THE HOT PATH ---------------------------
+    def optimize_parameters(self, current_iter: int, current_accum_iter: int, apply_gradient: bool) -> None:
+        assert self.lq is not None and self.gt is not None
+        if self.net_d is not None:
+            for p in self.net_d.parameters():
+                p.requires_grad = False
+        n_samples = self.gt.shape[0]
+        self.loss_samples += n_samples
+        net = self.net_g
+        hip_net = hasattr(net, "forward_hip")
+        lq, gt = self.lq, self.gt
+        if lq.dtype != torch.float32:
+            lq, gt = lq.float(), gt.float()
+        gt = gt.contiguous()
+
+        if hip_net:
+            out = net.forward_hip(lq, train=True)
+            out_leaf = None
+        else:  # foreign generator (stock nn.Module from the open plugin surface): ordinary autograd
+            with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
+                out = net(lq)
+        self.output = out.detach()
+        gout = torch.empty_like(self.output)
+        first = True                      # gout not written yet
+        scal = self._scal                 # device-resident scalars of this step
+        scal.zero_()
+        TOTAL = 63                        # scal[TOTAL] accumulates l_g_total
+        total = scal[TOTAL:TOTAL + 1]
+        keys: list[str] = []              # log key -> scal[i]
+        acc = self.accum_iters
+        skip_d_update = False
+        foreign_total = None
+
+        for label, loss in self.losses.items():
+            w = abs(loss.loss_weight)
+            if loss.loss_weight < 0:
+                raise NotImplementedError("negative loss_weight (bicubic-LQ target, sr_model.py:503-516) is not on the HIP path yet")
+            slot = len(keys)
+            if hasattr(loss, "hip_value_and_grad") and label != "l_g_gan":
+                # fused head.  scalar head: total += loss*w/acc ; dict head: total += v*w*acc  (sr_model.py:654-663)
+                is_dict = getattr(loss, "returns_dict", False)
+                k = float(acc) if is_dict else 1.0 / acc
+                subs = loss.hip_value_and_grad(self.output, gt, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
+                                               grad_weight=w * k, grad=gout, first=first)
+                keys += [f"{label}_{sub}" for sub in subs] if subs else [label]
+                first = False
+            else:
+                # foreign head (any registered nn.Module, incl. GAN on a stock discriminator): one-node autograd from the output
+                if out_leaf is None:
+                    out_leaf = self.output.clone().requires_grad_(True) if hip_net else out
+                with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
+                    if label == "l_g_gan":
+                        assert self.net_d is not None
+                        val = loss(self.net_d(out_leaf), True, is_disc=False)
+                    else:
+                        val = loss(out_leaf, gt)
+                items = [(f"{label}_{sub}", v, float(acc)) for sub, v in val.items()] if isinstance(val, dict) else [(label, val, 1.0 / acc)]
+                for key, v, k in items:
+                    wv = v * w
+                    foreign_total = wv * k if foreign_total is None else foreign_total + wv * k
+                    scal[len(keys)] = wv.detach().float()
+                    keys.append(key)
+
+        if foreign_total is not None:
+            total += foreign_total.detach().float()
+            if hip_net:
+                (g_foreign,) = torch.autograd.grad(foreign_total, out_leaf)
+                if first:
+                    gout.copy_(g_foreign)
+                else:
+                    flat_g, flat_f = gout.view(-1), g_foreign.contiguous().view(-1)
+                    n4 = flat_g.numel() // 4
+                    ops.axpby(ops.view(flat_g[: n4 * 4].view(n4, 4)), 1.0, ops.view(flat_f[: n4 * 4].view(n4, 4)), 1.0,
+                              ops.view(flat_g[: n4 * 4].view(n4, 4)), n4)
+                    if flat_g.numel() % 4:
+                        flat_g[n4 * 4:] += flat_f[n4 * 4:]
+                first = False
+            else:
+                foreign_total.backward()
+        nloss = len(keys)
+        assert nloss < 56, "too many loss terms for the scalar block"
+        GN_G, LD_REAL, LD_FAKE, GN_D = 56, 57, 58, 59
+        idx = list(range(nloss)) + [TOTAL]
+        keys.append("l_g_total")
+
+        if hip_net:
+            net.backward_hip(gout)
+
+        rank, world = get_dist_info()
+        if apply_gradient:
+            if hip_net:
+                parr, garr = net.flat_parameters()
+                if world > 1:
+                    allreduce_flat_(garr)
+                    # DDP averages: fold 1/world into the arena once (tiny vs the step)
+                    gv = garr.view(-1, 4)
+                    ops.axpby(ops.view(gv), 1.0 / world, ops.NULL_VIEW, 0.0, ops.view(gv), gv.shape[0])
+                ops.sumsq_norm(garr, scal[GN_G:GN_G + 1])
+                self._gnorm = scal[GN_G:GN_G + 1]
+                keys.append("grad_norm_g")
+                idx.append(GN_G)
+                ema_arena, ema_decay = None, 1.0
+                if self.net_g_ema is not None:
+                    d = self.net_g_ema.advance()
+                    ema_arena = self.net_g_ema.ema_arena()
+                    if d is None or ema_arena is None:
+                        ema_arena = None
+                        if d is not None:
+                            self._deferred_ema = d
+                    else:
+                        ema_decay = d
+                if isinstance(self.optimizer_g, AdamW):
+                    self.optimizer_g.set_step_extras(ema_arena=ema_arena, ema_decay=ema_decay,
+                                                     clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=self._gnorm)
+                    self.optimizer_g.step()
+                else:
+                    if self.grad_clip:
+                        torch.nn.utils.clip_grad_norm_(net.parameters(), self.grad_clip_threshold)
+                    self.optimizer_g.step()
+                    garr.zero_()
+                    if self.net_g_ema is not None and ema_arena is not None:
+                        self.net_g_ema._lerp(ema_decay)
+            else:
+                if world > 1:
+                    for p in net.parameters():
+                        if p.grad is not None:
+                            torch.distributed.all_reduce(p.grad)
+                            p.grad.div_(world)
+                if self.grad_clip:
+                    torch.nn.utils.clip_grad_norm_(net.parameters(), self.grad_clip_threshold)
+                self.optimizer_g.step()
+                self.optimizer_g.zero_grad()
+                if self.net_g_ema is not None:
+                    self.net_g_ema.update()
+            self.optimizers_skipped[0] = False
+
+        # ---- discriminator update (sr_model.py:725-808); stock-PyTorch D on the open plugin surface -------------
+        cri_gan = self.losses.get("l_g_gan")
+        if self.net_d is not None and cri_gan is not None and self.optimizer_d is not None and not skip_d_update:
+            for p in self.net_d.parameters():
+                p.requires_grad = True
+            with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
+                real_d_pred = self.net_d(gt)
+                fake_d_pred = self.net_d(self.output.detach())
+                l_d_real = cri_gan(real_d_pred, True, is_disc=True)
+                l_d_fake = cri_gan(fake_d_pred, False, is_disc=True)
+                l_d_total = (l_d_real + l_d_fake) * cri_gan.loss_weight
+            (l_d_total / acc).backward()
+            scal[LD_REAL] = l_d_real.detach().float()
+            scal[LD_FAKE] = l_d_fake.detach().float()
+            keys += ["l_d_real", "l_d_fake"]
+            idx += [LD_REAL, LD_FAKE]
+            if apply_gradient:
+                if world > 1:
+                    for p in self.net_d.parameters():
+                        if p.grad is not None:
+                            torch.distributed.all_reduce(p.grad)
+                            p.grad.div_(world)
+                gn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad, 2) for p in self.net_d.parameters()
+                                                           if p.grad is not None]))
+                scal[GN_D] = gn
+                keys.append("grad_norm_d")
+                idx.append(GN_D)
+                if self.grad_clip:
+                    torch.nn.utils.clip_grad_norm_(self.net_d.parameters(), self.grad_clip_threshold)
+                self.optimizer_d.step()
+                self.optimizer_d.zero_grad()
+
+        # device-resident log values of this step; read back lazily by get_current_log()
+        self._pending.append((keys, scal[idx], n_samples))
+        if len(self._pending) >= 64:
+            self._flush_pending()
+
+    # ------------------------------------------------------------------ inference / io -----------------------------
+    @torch.no_grad()
+    def test(self) -> None:
+        net = self.net_g_ema.ema_model if self.net_g_ema is not None else self.net_g
+        assert self.lq is not None
+        lq = self.lq.float()
+        self.output = net.forward_hip(lq, train=False) if hasattr(net, "forward_hip") else net(lq)
+
+    def load_network(self, net: nn.Module, load_path: str, strict: bool = True, param_key: str | None = None) -> None:
+        """safetensors / .pth state dicts (base_model.py:570-648); `param_key` falls back params_ema -> params -> flat."""
+        if load_path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+
+            sd = load_file(load_path)
+        else:
+            sd = torch.load(load_path, map_location="cpu", weights_only=True)
+            for k in ([param_key] if param_key else []) + ["params_ema", "params"]:
+                if isinstance(sd, dict) and k in sd and isinstance(sd[k], dict):
+                    sd = sd[k]
+                    break
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        net.load_state_dict(sd, strict=strict)
+
+    def save_network(self, net: nn.Module, path: str, fmt: str = "safetensors") -> None:
+        sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        if fmt == "safetensors":
+            from safetensors.torch import save_file
+
+            save_file(sd, path)
+        else:
+            torch.save(sd, path)
+
+    def save(self, epoch: int, current_iter: int) -> None:
+        """EMA net -> models/, raw net_g/net_d -> models/resume_models/ (sr_model.py:1174-1205)."""
+        p = self.opt.path
+        fmt = self.opt.logger.save_checkpoint_format if self.opt.logger is not None else "safetensors"
+        if p.models is None:
+            raise ValueError("opt.path.models is not set")
+        ext = "safetensors" if fmt == "safetensors" else "pth"
+        if self.net_g_ema is not None:
+            self.save_network(self.net_g_ema.ema_model, os.path.join(p.models, f"net_g_ema_{current_iter}.{ext}"), fmt)
+            self.save_network(self.net_g, os.path.join(p.resume_models or p.models, f"net_g_{current_iter}.{ext}"), fmt)
+        else:
+            self.save_network(self.net_g, os.path.join(p.models, f"net_g_{current_iter}.{ext}"), fmt)
+        if self.net_d is not None:
+            self.save_network(self.net_d, os.path.join(p.resume_models or p.models, f"net_d_{current_iter}.{ext}"), fmt)

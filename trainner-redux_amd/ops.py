@@ -181,17 +181,25 @@ def scratch(device, nfloats: int = 4096) -> torch.Tensor:
     return t
 
 
-def pixel_loss(kind: int, pred: torch.Tensor, target: torch.Tensor, weight: float, loss_out: torch.Tensor, *, eps: float = 1e-12,
-               accumulate_loss=False, grad: torch.Tensor | None = None, accumulate_grad=False):
-    _need_cuda(pred, target, loss_out, grad)
+def pixel_loss(kind: int, pred: torch.Tensor, target: torch.Tensor, value_out: torch.Tensor, *, value_weight: float = 1.0,
+               total_out: torch.Tensor | None = None, total_weight: float = 0.0, grad: torch.Tensor | None = None,
+               grad_weight: float | None = None, accumulate_grad: bool = False, eps: float = 1e-12):
+    """value_out[0] = value_weight*mean ; total_out[0] += total_weight*mean ; grad (+)= grad_weight * dmean/dpred."""
+    _need_cuda(pred, target, value_out, grad, total_out)
     assert pred.shape == target.shape and pred.dtype == target.dtype and pred.is_contiguous() and target.is_contiguous()
-    assert loss_out.dtype == torch.float32
+    assert value_out.dtype == torch.float32 and (total_out is None or total_out.dtype == torch.float32)
+    d = L.PixelLossDesc()
+    d.kind, d.dtype = kind, dt_code(pred.dtype)
+    d.pred, d.target, d.numel = pred.data_ptr(), target.data_ptr(), pred.numel()
+    d.eps, d.value_weight, d.total_weight = eps, value_weight, total_weight
+    d.grad_weight = value_weight if grad_weight is None else grad_weight
+    d.value_out = value_out.data_ptr()
+    d.total_out = total_out.data_ptr() if total_out is not None else None
     if grad is not None:
         assert grad.is_contiguous() and grad.numel() == pred.numel()
-    L.check(L.lib().tr_pixel_loss(stream_ptr(), kind, pred.data_ptr(), target.data_ptr(), dt_code(pred.dtype), pred.numel(), weight, eps,
-                                  loss_out.data_ptr(), 1 if accumulate_loss else 0, grad.data_ptr() if grad is not None else None,
-                                  dt_code(grad.dtype) if grad is not None else 0, 1 if accumulate_grad else 0,
-                                  scratch(pred.device).data_ptr()), "tr_pixel_loss")
+        d.grad, d.grad_dtype, d.accumulate_grad = grad.data_ptr(), dt_code(grad.dtype), 1 if accumulate_grad else 0
+    d.partials = scratch(pred.device).data_ptr()
+    L.check(L.lib().tr_pixel_loss(stream_ptr(), C.byref(d)), "tr_pixel_loss")
 
 
 def sumsq_norm(x: torch.Tensor, out: torch.Tensor):

@@ -1,0 +1,114 @@
+"""`build_optimizer` + the fused AdamW the hot path uses.
+
+Registry contract of /root/reference/traiNNer/optimizers/__init__.py:30-47: `OPTIMIZER_REGISTRY.get(type)(params, **opt)`.
+All of the reference's templates use `type: AdamW` (e.g. options/_templates/train/ESRGAN/ESRGAN_fidelity.yml:89-93).
+`AdamW` here is a `torch.optim.Optimizer` (param_groups / state_dict / LR schedulers keep working) whose `step()` is ONE
+kernel per parameter arena: gradient-norm clip scale, AdamW update, EMA lerp and zero_grad in a single HBM sweep.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any
+
+import torch
+
+from .. import ops
+from ..utils.registry import OPTIMIZER_REGISTRY
+
+__all__ = ["AdamW", "build_optimizer"]
+
+
+def _arena_of(t: torch.Tensor):
+    """(flat float32 tensor over the whole storage, element offset of `t` in it) when `t` is a contiguous
+    slice of a larger buffer (a parameter arena), else None."""
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        return None
+    st = t.untyped_storage()
+    nfloats = st.nbytes() // 4
+    if nfloats <= t.numel():
+        return None
+    flat = torch.empty(0, dtype=torch.float32, device=t.device).set_(st, 0, (nfloats,))
+    return flat, t.storage_offset()
+
+
+@OPTIMIZER_REGISTRY.register()
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, **unused: Any):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._flat: dict = {}
+        self._ema_arena = None
+        self._ema_decay = 1.0
+        self._clip = 0.0
+        self._grad_norm = None
+        self._grad_scale_world = 1
+
+    # -- fused extras -------------------------------------------------------------------------------
+    def set_step_extras(self, *, ema_arena: torch.Tensor | None = None, ema_decay: float = 1.0, clip: float = 0.0,
+                        grad_norm: torch.Tensor | None = None) -> None:
+        """EMA target / decay, clip threshold and the device-resident gradient norm for the NEXT step()."""
+        self._ema_arena, self._ema_decay, self._clip, self._grad_norm = ema_arena, ema_decay, clip, grad_norm
+
+    def _group_arenas(self, group):
+        """Split a param group into arenas (fused) and loose tensors."""
+        arenas: dict = defaultdict(list)
+        loose = []
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            a = _arena_of(p.data)
+            g = _arena_of(p.grad)
+            if a is None or g is None or a[1] != g[1] or a[0].numel() != g[0].numel():
+                loose.append(p)
+            else:
+                arenas[(a[0].data_ptr(), g[0].data_ptr())].append((p, a[0], g[0]))
+        return arenas, loose
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            arenas, loose = self._group_arenas(group)
+            for key, members in arenas.items():
+                pa, ga = members[0][1], members[0][2]
+                covered = sum((p.numel() + 3) // 4 * 4 for p, _, _ in members)
+                st = self._flat.get(key)
+                if covered != pa.numel():
+                    loose.extend(p for p, _, _ in members)  # a partial arena: fall back to per-tensor launches
+                    continue
+                if st is None:
+                    st = dict(step=0, m=torch.zeros_like(pa), v=torch.zeros_like(pa))
+                    self._flat[key] = st
+                    for p, _, _ in members:  # expose views so state_dict()/load_state_dict() see per-parameter state
+                        off = p.data.storage_offset()
+                        self.state[p] = dict(step=torch.tensor(0.0), exp_avg=st["m"][off:off + p.numel()].view(p.shape),
+                                             exp_avg_sq=st["v"][off:off + p.numel()].view(p.shape))
+                st["step"] += 1
+                ema = self._ema_arena if (self._ema_arena is not None and self._ema_arena.numel() == pa.numel()) else None
+                ops.adamw_ema(pa, ga, st["m"], st["v"], ema, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
+                              weight_decay=group["weight_decay"], step=st["step"], ema_decay=self._ema_decay, clip=self._clip,
+                              grad_norm=self._grad_norm, zero_grad=True)
+                for p, _, _ in members:
+                    self.state[p]["step"] += 1
+            for p in loose:
+                st = self.state[p]
+                if not st:
+                    st.update(step=torch.tensor(0.0), exp_avg=torch.zeros_like(p.data), exp_avg_sq=torch.zeros_like(p.data))
+                st["step"] += 1
+                if not p.data.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("fused AdamW needs contiguous parameters and gradients")
+                ops.adamw_ema(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], None, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
+                              weight_decay=group["weight_decay"], step=int(st["step"]), clip=self._clip, grad_norm=self._grad_norm,
+                              zero_grad=False)
+        return loss
+
+
+def build_optimizer(params, opt: dict[str, Any]) -> torch.optim.Optimizer:
+    opt = dict(opt)
+    optim_type = opt.pop("type")
+    return OPTIMIZER_REGISTRY.get(optim_type)(params, **opt)
