@@ -92,6 +92,12 @@ typedef struct tr_conv3x3_desc {
 
 int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
 
+/* Gradient of a <=4-channel stem conv (VGG19 conv1_1, perceptual_fp16_loss.py:272-274) with respect to the NCHW fp32
+ * image: conv_backward_input + adjoint of zero/replicate padding + per-channel scale (1/std of the input
+ * normalisation, host pointer, may be NULL); dst (+)= result.  Weights are the fp32 OIHW master tensor. */
+int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_oihw, int cout, int cin, int n, int h, int w, int pad_mode,
+                           const float* ch_scale_host, float* dst_nchw, int accumulate);
+
 /* ---- weight packing -------------------------------------------------------------------------
  * Master weights stay fp32 OIHW (the state-dict layout the reference saves and spandrel loads,
  * base_model.py:395-482).  A segment copies the sub-block src[o_off:o_off+o_cnt, i_off:i_off+i_cnt]

@@ -81,7 +81,7 @@ def test_esrgan_fp32_forward_backward(cuda, cfg):
     worst = errs[-1]
     # median is rounding-level; a single tensor can sit higher when a LeakyReLU input lands within 1e-7 of zero
     # (its derivative flips between 1 and 0.2 between two summation orders)
-    assert errs[len(errs) // 2] < 2e-5 and worst < 1e-3, (errs[len(errs) // 2], worst)
+    assert errs[len(errs) // 2] < 5e-5 and worst < 1e-3, (errs[len(errs) // 2], worst)
     print(f"fp32 {cfg}: fwd rel-L2 {rel_l2(out.cpu(), ref_out):.2e}, worst grad rel-L2 {worst:.2e}")
 
 

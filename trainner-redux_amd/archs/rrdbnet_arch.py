@@ -275,7 +275,9 @@ class RRDBNet(nn.Module):
         ws.gT = e(n, h, w, nf)
         ws.gF = e(n, h, w, nf)
         need = 0
-        for (hh, ww, cin, cout) in [(h, w, nf + 4 * gc, nf), (ws.H, ws.W, nf, nf)] + [(h << j, w << j, nf, nf) for j in range(self.n_up + 1)]:
+        shapes = [(h, w, nf + k * gc, gc) for k in range(4)] + [(h, w, nf + 4 * gc, nf), (h, w, self.in_nc, nf), (ws.H, ws.W, nf, nf),
+                  (ws.H, ws.W, nf, self.out_nc)] + [(h << j, w << j, nf, nf) for j in range(self.n_up + 1)]
+        for (hh, ww, cin, cout) in shapes:
             need = max(need, ops.wgrad_workspace_bytes(n, hh, ww, cin, cout))
         ws.wg = torch.empty(need // 4 + 16, dtype=torch.float32, device=dev)
 

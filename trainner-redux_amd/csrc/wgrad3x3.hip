@@ -32,6 +32,7 @@ struct WgArgs {
     int up, replicate;
     tr_view in, gy;
     float* partials;
+    float* db_partials;   // [slot][ncg][CG] or null
     int ntx, nty, ntiles, nslots, nchunks, ncg;
 };
 
@@ -63,6 +64,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][t][i] = 0.f;
+
+    // bias gradient rides along in the (chunk 0, ky 0) wave: column sums of the gy fragments it already holds
+    const bool do_bias = (a.db_partials != nullptr) & (chunk == 0) & (ky == 0);
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
 
     const char* in_base = (const char*)a.in.ptr;
     const char* gy_base = (const char*)a.gy.ptr;
@@ -136,6 +143,12 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
                             hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gl + gp * GPIX_BYTES + bo));
                         }
                         af[t2] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        if (do_bias) {
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) sacc += tr::bf16_to_f32((unsigned short)af[t2][e]);
+                            bsum[t2] += sacc;
+                        }
                     }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
@@ -158,7 +171,10 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
                     float af[NT];
 #pragma unroll
                     for (int t2 = 0; t2 < NT; ++t2)
+                    {
                         af[t2] = *(const float*)(gl + (r * 32 + kp * 2 + lh) * GPIX_BYTES + (t2 * 32 + lr) * 4);
+                        if (do_bias) bsum[t2] += af[t2];
+                    }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float bf = *(const float*)(xl + ((r + ky) * HALO_W + kp * 2 + lh + kx) * XPIX_BYTES + lr * 4);
@@ -171,6 +187,13 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
         }
     }
 
+    if (do_bias) {
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) {
+            const float v = bsum[t2] + __shfl_xor(bsum[t2], 32, 64);   // the two lane halves hold disjoint pixels of one channel
+            if (lh == 0) a.db_partials[((int64_t)slot * a.ncg + cg) * CG + t2 * 32 + lr] = v;
+        }
+    }
     // partial block: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
     float* dst = a.partials + (((int64_t)slot * a.nchunks + chunk) * a.ncg + cg) * (CG * 9 * CKW);
 #pragma unroll
@@ -197,46 +220,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int64_t blk = (int64_t)cgw * 9 * CKW;
         const float* p = partials + ((int64_t)chunk * ncg + cg) * blk + ((int64_t)col * 9 + tap) * CKW + cil;
         const int64_t stride = (int64_t)nchunks * ncg * blk;
-        float s = 0.f;
-        for (int k = 0; k < nslots; ++k) s += p[k * stride];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // fixed association: reproducible
+        int k = 0;
+        for (; k + 4 <= nslots; k += 4) {
+            s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
+        }
+        for (; k < nslots; ++k) s0 += p[k * stride];
+        const float s = (s0 + s1) + (s2 + s3);
         float* o = dw + ((int64_t)co * cin + ci) * 9 + tap;
         *o = accumulate ? *o + s : s;
     }
 }
 
-// bias gradient: column sums of gy over all pixels
-__global__ __launch_bounds__(256) void colsum_kernel(tr_view gy, int64_t npix, int c, float* __restrict__ partials) {
-    // thread = (pixel lane, channel); block covers a contiguous pixel range
-    extern __shared__ float sh[];
-    const int lanes = 256 / c > 0 ? 256 / c : 1;       // pixel lanes per block (c <= 256)
-    const int ch = threadIdx.x % c, pl = threadIdx.x / c;
-    float s = 0.f;
-    if (pl < lanes) {
-        const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
-        const int64_t b = (int64_t)blockIdx.x * per, e = min(b + per, npix);
-        for (int64_t p = b + pl; p < e; p += lanes) s += tr::view_load(gy, p, ch);
+// bias gradient: sum the per-slot column sums written by the (chunk 0, ky 0) waves
+__global__ __launch_bounds__(64) void db_finish_kernel(const float* __restrict__ partials, int nslots, int ncg, int cgw, int cout,
+                                                       float* __restrict__ db, int accumulate) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= cout) return;
+    const int cg = co / cgw, col = co - cg * cgw;
+    const float* p = partials + (int64_t)cg * cgw + col;
+    const int64_t stride = (int64_t)ncg * cgw;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= nslots; k += 4) {
+        s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
     }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < c) {
-        float t = 0.f;
-        for (int k = 0; k < lanes; ++k) t += sh[k * c + threadIdx.x];
-        partials[(int64_t)blockIdx.x * c + threadIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partials, int nblocks, int c, float* __restrict__ db,
-                                                             int accumulate) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    float s = 0.f;
-    for (int k = 0; k < nblocks; ++k) s += partials[(int64_t)k * c + ch];
-    db[ch] = accumulate ? db[ch] + s : s;
+    for (; k < nslots; ++k) s0 += p[k * stride];
+    const float s = (s0 + s1) + (s2 + s3);
+    db[co] = accumulate ? db[co] + s : s;
 }
 
 struct Plan {
     int ntx, nty, ntiles, nslots, nchunks, ncg, cgw;
-    size_t dw_floats, db_blocks, db_floats;
+    size_t dw_floats, db_floats;
 };
 
 Plan make_plan(int n, int h, int w, int cin, int cout) {
@@ -247,12 +263,11 @@ Plan make_plan(int n, int h, int w, int cin, int cout) {
     p.nchunks = (cin + CKW - 1) / CKW;
     p.cgw = cout > 32 ? 64 : 32;
     p.ncg = (cout + p.cgw - 1) / p.cgw;
-    int target = 1024 / (p.nchunks * p.ncg);
+    int target = 768 / (p.nchunks * p.ncg);      // ~3 workgroups of 3 waves per CU
     if (target < 1) target = 1;
     p.nslots = p.ntiles < target ? p.ntiles : target;
     p.dw_floats = (size_t)p.nslots * p.nchunks * p.ncg * p.cgw * 9 * CKW;
-    p.db_blocks = 256;
-    p.db_floats = p.db_blocks * (size_t)cout;
+    p.db_floats = (size_t)p.nslots * p.ncg * p.cgw;
     return p;
 }
 
@@ -293,7 +308,6 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout);
     TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
                "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
-    TR_REQUIRE(d->db == nullptr || d->cout <= 256, TR_EUNSUPPORTED, "tr_wgrad3x3: bias gradient supports cout <= 256");
 
     WgArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w;
@@ -303,6 +317,7 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     a.replicate = d->pad_mode == TR_PAD_REPLICATE;
     a.in = d->in; a.gy = d->gy;
     a.partials = d->partials;
+    a.db_partials = d->db ? d->partials + p.dw_floats : nullptr;
     a.ntx = p.ntx; a.nty = p.nty; a.ntiles = p.ntiles; a.nslots = p.nslots; a.nchunks = p.nchunks; a.ncg = p.ncg;
     hipStream_t st = (hipStream_t)stream;
     int rc;
@@ -319,15 +334,9 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
         if (rc) return rc;
     }
     if (d->db) {
-        float* dbp = d->partials + p.dw_floats;
-        const int64_t npix = (int64_t)d->n * d->h * d->w;
-        int nb = (int)p.db_blocks;
-        if (npix < nb) nb = (int)npix;
-        hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 256 * sizeof(float), st, d->gy, npix, d->cout, dbp);
-        rc = tr::launch_status("tr_wgrad3x3(colsum)");
-        if (rc) return rc;
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3((d->cout + 255) / 256), dim3(256), 0, st, dbp, nb, d->cout, d->db, d->accumulate);
-        rc = tr::launch_status("tr_wgrad3x3(colsum finish)");
+        hipLaunchKernelGGL(db_finish_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, st, d->partials + p.dw_floats, p.nslots, p.ncg, p.cgw,
+                           d->cout, d->db, d->accumulate);
+        rc = tr::launch_status("tr_wgrad3x3(bias finish)");
     }
     return rc;
 }

@@ -129,6 +129,8 @@ class SRModel:
             if float(loss["loss_weight"]) != 0:
                 label = loss_type_to_label(loss["type"])
                 self.losses[label] = build_loss(loss).to(self.device)
+                if hasattr(self.losses[label], "set_compute_dtype"):
+                    self.losses[label].set_compute_dtype(self.compute_dtype)
         assert self.losses, "At least one loss must be defined."
         self.setup_optimizers()
         self.setup_schedulers()

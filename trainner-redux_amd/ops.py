@@ -153,6 +153,15 @@ def nhwc_to_nchw_scaled(src_view: L.View, dst: torch.Tensor, inv_std, accumulate
             "tr_nhwc_to_nchw_scaled")
 
 
+def conv3x3_dgrad_image(gy: L.View, w_oihw: torch.Tensor, n, h, w, dst: torch.Tensor, *, pad_mode=L.PAD_ZEROS, ch_scale=None,
+                        accumulate=False):
+    assert w_oihw.dtype == torch.float32 and w_oihw.is_contiguous() and dst.dtype == torch.float32 and dst.is_contiguous()
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    sc = (C.c_float * cin)(*[float(v) for v in ch_scale]) if ch_scale is not None else None
+    L.check(L.lib().tr_conv3x3_dgrad_image(stream_ptr(), gy, w_oihw.data_ptr(), cout, cin, n, h, w, pad_mode, sc, dst.data_ptr(),
+                                           1 if accumulate else 0), "tr_conv3x3_dgrad_image")
+
+
 def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int):
     L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix), "tr_axpby")
 
