@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.pt from the reference files that load by path in this container.
+
+Run HERE only (needs /root/reference): `python tests/golden/make_golden.py`.  Nothing from the reference is
+copied: each torch-only file is imported by path under stub parent packages, executed on
+seeded inputs, and only input / output TENSORS plus a manifest are written.  The GPU box never reads /root/reference.
+
+Fixtures
+  pixel_gan_losses.pt   basic_loss.{L1Loss,MSELoss,CharbonnierLoss} (mean / sum) and gan_loss.GANLoss
+                        (vanilla, lsgan, hinge, wgan, wgan_softplus x real/fake x is_disc)
+  registry.pt           registry key behaviour (lower-casing, suffix fallback, duplicate assertion)
+  sampler.pt            data_sampler.EnlargedSampler index streams (epoch-seeded permutation, rank stride)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    for n in ("traiNNer", "traiNNer.utils", "traiNNer.losses", "traiNNer.data"):
+        _stub(n)
+    # torchvision is absent: basic_loss only needs the names at import time
+    tv = _stub("torchvision")
+    tvt = _stub("torchvision.transforms")
+    tvt.GaussianBlur = object
+    tvt.InterpolationMode = types.SimpleNamespace(BICUBIC="bicubic")
+    tvt.v2 = types.SimpleNamespace()
+    tv.transforms = tvt
+    reg = _load("traiNNer.utils.registry", "traiNNer/utils/registry.py")
+    cu = _stub("traiNNer.utils.color_util")
+    cu.rgb2ycbcr_pt = cu.rgb_to_luma = lambda *a, **k: None
+    hs = _stub("traiNNer.utils.hsluv")
+    hs.rgb_to_hsluv = lambda *a, **k: None
+    _load("traiNNer.losses.loss_util", "traiNNer/losses/loss_util.py")
+    bl = _load("traiNNer.losses.basic_loss", "traiNNer/losses/basic_loss.py")
+    gl = _load("traiNNer.losses.gan_loss", "traiNNer/losses/gan_loss.py")
+
+    g = torch.Generator().manual_seed(20261004)
+    pred = torch.rand(2, 3, 24, 20, generator=g)
+    target = torch.rand(2, 3, 24, 20, generator=g)
+    fix = {"pred": pred, "target": target, "pixel": {}, "gan": {}}
+    for name, cls in (("l1", bl.L1Loss), ("mse", bl.MSELoss), ("charbonnier", bl.CharbonnierLoss)):
+        for red in ("mean", "sum"):
+            p = pred.clone().requires_grad_(True)
+            v = cls(loss_weight=1.0, reduction=red)(p, target)
+            v.backward()
+            fix["pixel"][f"{name}/{red}"] = {"value": v.detach(), "grad": p.grad.clone()}
+    logits = torch.randn(2, 1, 8, 8, generator=g)
+    fix["logits"] = logits
+    for gt_ in ("vanilla", "lsgan", "hinge", "wgan", "wgan_softplus"):
+        m = gl.GANLoss(loss_weight=0.1, gan_type=gt_)
+        for real in (True, False):
+            for disc in (True, False):
+                fix["gan"][f"{gt_}/{int(real)}/{int(disc)}"] = m(logits, real, is_disc=disc).detach()
+    torch.save(fix, os.path.join(OUT, "pixel_gan_losses.pt"))
+
+    r = reg.Registry("t")
+
+    @r.register()
+    class FooBar:  # noqa: N801
+        pass
+
+    @r.register(suffix="traiNNer")
+    def baz():
+        pass
+
+    dup = False
+    try:
+        r.register(FooBar)
+    except AssertionError:
+        dup = True
+    missing = False
+    try:
+        r.get("nope")
+    except KeyError:
+        missing = True
+    torch.save({"keys": list(r.keys()), "get_FOOBAR": r.get("FOOBAR").__name__, "get_baz": r.get("baz").__name__, "contains_FooBar": "FooBar" in r,
+                "duplicate_asserts": dup, "missing_keyerror": missing,
+                "singletons": sorted(k for k in vars(reg) if k.endswith("_REGISTRY"))}, os.path.join(OUT, "registry.pt"))
+
+    ds = _load("traiNNer.data.data_sampler", "traiNNer/data/data_sampler.py")
+    out = {}
+    data = list(range(10))
+    for world in (1, 2, 4):
+        for rank in range(world):
+            s = ds.EnlargedSampler(data, world, rank, ratio=3)
+            for epoch in (0, 1):
+                s.set_epoch(epoch)
+                out[f"{world}/{rank}/{epoch}"] = torch.tensor(list(iter(s)))
+            out[f"{world}/{rank}/len"] = len(s)
+    torch.save(out, os.path.join(OUT, "sampler.pt"))
+    print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".pt")))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""CPU suite (no GPU): pins the oracle to the reference's own numbers and fixtures.
+
+  * parameter-count checksums from /root/reference/docs/source/benchmarks.md:64,221,42
+  * tests/golden/pixel_gan_losses.pt -- outputs of the reference's basic_loss.py / gan_loss.py (make_golden.py)
+  * behavioural invariants the reference's tests assert (tests/test_losses/test_losses.py:114-206,
+    tests/test_archs/test_archs.py:182-185,246-268)
+"""
+import os
+from collections import OrderedDict
+
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_esrgan_param_count_checksums():
+    from oracle import esrgan as OE
+
+    assert OE.param_count(OE.esrgan_hparams(scale=4)) == 16_697_987          # benchmarks.md:64
+    assert OE.param_count(OE.esrgan_hparams(scale=2)) == 16_703_171          # benchmarks.md:221 (pixel-unshuffle front)
+    assert OE.param_count(OE.esrgan_hparams(scale=4, num_filters=32, num_blocks=12)) == 5_021_155   # esrgan_lite, :42
+    hp = OE.esrgan_hparams(scale=4)
+    keys = list(OE.init_state_dict(hp).keys())
+    assert keys[0] == "model.0.weight" and "model.1.sub.0.RDB1.conv1.0.weight" in keys and "model.1.sub.23.weight" in keys
+    assert keys[-1] == "model.10.bias"
+
+
+@pytest.mark.parametrize("scale,kw", [(4, {}), (2, {}), (2, dict(use_pixel_unshuffle=False)), (1, {})])
+def test_esrgan_oracle_shape_and_one_step_is_finite(scale, kw):
+    """tests/test_archs/test_archs.py: output H, W == scale x input; one L1 + AdamW step leaves everything finite."""
+    from oracle import esrgan as OE, losses as OL, step as OS
+
+    hp = OE.esrgan_hparams(scale=scale, num_blocks=1, **kw)
+    sd = OE.init_state_dict(hp, 1)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    x = torch.rand(1, 3, 16, 16)
+    gt = torch.rand(1, 3, 16 * scale, 16 * scale)
+    st = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()))
+    out, ld, log, grads = OS.generator_step(params, lambda p, t: OE.forward(p, t, hp), {"l_g_l1": (OL.l1, 1.0)}, x, gt, st, None)
+    assert out.shape == gt.shape
+    assert all(torch.isfinite(g).all() for g in grads.values()) and all(torch.isfinite(p).all() for p in params.values())
+    assert set(ld) == {"l_g_l1", "l_g_total", "grad_norm_g"}
+
+
+def test_oracle_losses_match_reference_golden():
+    from oracle import losses as OL
+
+    fix = torch.load(os.path.join(GOLD, "pixel_gan_losses.pt"), weights_only=True)
+    pred, target, logits = fix["pred"], fix["target"], fix["logits"]
+    fns = {"l1": OL.l1, "mse": OL.mse, "charbonnier": OL.charbonnier}
+    for key, ref in fix["pixel"].items():
+        name, red = key.split("/")
+        p = pred.clone().requires_grad_(True)
+        v = fns[name](p, target, reduction=red)
+        v.backward()
+        assert torch.equal(v.detach(), ref["value"]), key
+        assert torch.equal(p.grad, ref["grad"]), key
+    for key, ref in fix["gan"].items():
+        gt_, real, disc = key.split("/")
+        v = OL.gan(logits, bool(int(real)), is_disc=bool(int(disc)), gan_type=gt_)
+        assert torch.equal(v, ref), key
+
+
+def test_loss_invariants_of_the_reference_tests():
+    from oracle import losses as OL, vgg as OV
+
+    black = torch.zeros(2, 3, 32, 32)
+    for fn in (OL.l1, OL.mse, OL.charbonnier):
+        assert float(fn(black, black)) <= 1e-5                                     # test_losses.py:114-128
+    sd = OV.synthetic_state_dict(0)
+    assert all(float(v) <= 1e-5 for v in OV.perceptual_loss(sd, black, black).values())
+    a, b = torch.rand(1, 3, 32, 32), torch.rand(1, 3, 32, 32)
+    one = OV.perceptual_loss(sd, a, b)
+    two = OV.perceptual_loss(sd, torch.cat([a, a]), torch.cat([b, b]))             # batch-duplication invariance, :185-206
+    for k in one:
+        assert abs(float(one[k]) - float(two[k])) < 1e-6
+    assert list(one.keys()) == ["conv1_2", "conv2_2", "conv3_4", "conv4_4", "conv5_4"]   # stage set, :130-179
+    with pytest.raises(ValueError):
+        OL.l1(a, b, reduction="bogus")
+
+
+def test_vgg_table_matches_torchvision_indices():
+    from oracle import vgg as OV
+
+    t = OV.conv_table()
+    assert len(t) == 16 and [i for _, i, _, _ in t][:5] == [0, 2, 5, 7, 10] and t[-1][1] == 34
+    assert [c for _, _, _, c in t] == [64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 512, 512]
+
+
+def test_adamw_oracle_equals_torch_optim():
+    from oracle import step as OS
+
+    p = torch.randn(257)
+    q = p.clone().requires_grad_(True)
+    o = torch.optim.AdamW([q], lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    st = OS.AdamWState(OrderedDict(p=p), 2e-4, (0.9, 0.99), 1e-8, 0.01)
+    for _ in range(7):
+        g = torch.randn(257)
+        q.grad = g.clone()
+        o.step()
+        st.step(OrderedDict(p=p), OrderedDict(p=g))
+    assert torch.equal(p, q.detach())
+
+
+def test_bf16_policy_sits_closer_to_fp32_than_autocast():
+    """oracle/precision.py: the HIP bf16 contract (bf16 MFMA operands, fp32 everything else) vs the reference's AMP path."""
+    from oracle import esrgan as OE
+    from oracle.precision import BF16_OPS
+
+    hp = OE.esrgan_hparams(scale=4, num_blocks=4)
+    sd = OE.init_state_dict(hp, 0)
+    x = torch.rand(1, 3, 16, 16)
+    with torch.no_grad():
+        y = OE.forward(sd, x, hp)
+        yb = OE.forward(sd, x, hp, BF16_OPS)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ya = OE.forward(sd, x, hp).float()
+    rel = lambda a: ((a - y).norm() / y.norm()).item()  # noqa: E731
+    assert rel(yb) < rel(ya) < 5e-2
