@@ -8,7 +8,8 @@
 // Mapping to gfx950 (DESIGN.md "conv3x3 kernel"):
 //   * one workgroup = 4 waves = a (4*R) x 32 pixel tile x one group of 32/64 output channels;
 //   * the K loop walks the input channels in 64-byte chunks (32 bf16 / 16 f32 channels); per
-//     chunk the (4R+2) x 34 pixel halo and the 9 x CG x 64 B weight slab are staged in LDS
+//     chunk the (4R+2) x 34 pixel halo and the 9 x CG x 64 B weight slab are staged in LDS by LDS-DMA
+//     (buffer_load ... lds, two stages: chunk c+1 lands while chunk c feeds the MFMAs, one barrier per chunk)
 //     (16-byte slots XOR-swizzled by (row>>2)&3 so every ds_read_b128 of an MFMA operand is
 //     bank-conflict free) and all nine taps are read out of the same halo image by address
 //     offset -- im2col is never materialised;
@@ -17,6 +18,8 @@
 //     epilogue (bias, LeakyReLU/ReLU, two scaled residuals, activation-derivative mask, dual
 //     dtype stores) works on 8/16-byte NHWC vectors.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -38,12 +41,157 @@ struct ConvArgs {
     tr_view in, out, out2, res1, res2, mask;
     const char* wpacked;
     const float* bias;
-    int ntx, nty, nchunks;
+    int ntx, nty, nchunks, ncg;
     int vec_out, vec_out2, vec_res1, vec_res2, vec_mask;
+    int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores
 };
 
+
+// ---- 9 taps x one K-chunk of MFMAs out of the staged LDS image (hl: halo, wl: weight slab) --------------------------
 template <int CT, int NT, int R>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int wv, int lr, int lh) {
+    constexpr int CGW = NT * 32;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int slot = q * 2 + lh;
+            if constexpr (CT == TR_BF16) {
+                bf16x8 wa[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int row = tap * CGW + t * 32 + lr;
+                    wa[t] = *(const bf16x8*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
+                    const bf16x8 xb = *(const bf16x8*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb, acc[r][t], 0, 0, 0);
+                }
+            } else {
+                f32x4 wa[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int row = tap * CGW + t * 32 + lr;
+                    wa[t] = *(const f32x4*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
+                    const f32x4 xb = *(const f32x4*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][e], xb[e], acc[r][t], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // bound the live operand fragments to one tap (VGPR budget)
+    }
+}
+
+// ---- fused epilogue: bias, activation, two scaled residuals, derivative mask, dual-dtype NHWC stores ------------------
+// The MFMA accumulator holds, per lane, ONE pixel and 16 scattered channel quads, so storing from it directly issues
+// 8-byte stores to 64 different pixel records per instruction (measured: the stores of a 64->64 conv at 1024^2 cost
+// 0.75 of its 2.0 ms).  Each wave therefore transposes one 32-pixel row at a time through a private LDS strip
+// ([pixel][CGW] fp32, rows padded by 16 B against bank conflicts) and then walks it with lane = (pixel, 4-channel
+// segment): residual / mask loads and the stores become 8-16 B per lane over contiguous pixel records.
+template <int NT, int R>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
+                                              int l, bool wave_active) {
+    constexpr int CGW = NT * 32;
+    constexpr int ROWB = CGW * 4 + 16;
+    constexpr int SEGS = CGW / 4;            // 16-byte fp32 segments per pixel
+    constexpr int ITER = 32 * SEGS / 64;
+    __syncthreads();                          // every wave is done with the staged operands: LDS is free
+    if (!wave_active || (a.dbg & 4)) return;
+    const int lr = l & 31, lh = l >> 5;
+    char* strip = smem + wv * (32 * ROWB);
+    const bool generic = !(a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_res2 && a.vec_mask);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int oy = y0 + wv * R + r;
+        if (oy >= a.h) break;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(strip + lr * ROWB + (t * 32 + q * 8 + lh * 4) * 4) =
+                    make_float4(acc[r][t][q * 4 + 0], acc[r][t][q * 4 + 1], acc[r][t][q * 4 + 2], acc[r][t][q * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int idx = i * 64 + l;
+            const int p = idx / SEGS, seg = idx - p * SEGS;
+            const int ox = x0 + p;
+            const int co = cg * CGW + seg * 4;
+            const float4 raw = *(const float4*)(strip + p * ROWB + seg * 16);
+            if (ox >= a.w || co >= a.cout) continue;
+            const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
+            float v[4] = {raw.x, raw.y, raw.z, raw.w};
+            const bool full = (co + 3) < a.cout;
+            if (a.bias) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (co + k < a.cout) v[k] += a.bias[co + k];
+            }
+            if (a.act == TR_ACT_LRELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
+            } else if (a.act == TR_ACT_RELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            if (full && !generic) {
+                if (a.res1.ptr) {
+                    const float4 rr = tr::view_load4(a.res1, pix, co, true);
+                    v[0] = v[0] * a.scale1 + a.rs1 * rr.x; v[1] = v[1] * a.scale1 + a.rs1 * rr.y;
+                    v[2] = v[2] * a.scale1 + a.rs1 * rr.z; v[3] = v[3] * a.scale1 + a.rs1 * rr.w;
+                }
+                if (a.res2.ptr) {
+                    const float4 rr = tr::view_load4(a.res2, pix, co, true);
+                    v[0] = v[0] * a.scale2 + a.rs2 * rr.x; v[1] = v[1] * a.scale2 + a.rs2 * rr.y;
+                    v[2] = v[2] * a.scale2 + a.rs2 * rr.z; v[3] = v[3] * a.scale2 + a.rs2 * rr.w;
+                }
+                if (a.mask.ptr) {
+                    const float4 mm = tr::view_load4(a.mask, pix, co, true);
+                    v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
+                    v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
+                }
+                tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), true);
+                if (a.out2.ptr) {
+                    const float sc = a.out2_scale;
+                    tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
+                }
+            } else {
+                for (int k = 0; k < 4 && co + k < a.cout; ++k) {
+                    float x = v[k];
+                    if (a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + k);
+                    if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
+                    if (a.mask.ptr) x *= tr::view_load(a.mask, pix, co + k) > 0.f ? 1.f : a.mask_slope;
+                    tr::view_store(a.out, pix, co + k, x);
+                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, x * a.out2_scale);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ---- variant A: register-staged (global -> VGPR -> LDS), persistent over tiles ------------------------------------------
+// A workgroup walks tiles (cout group fastest, so neighbours in the walk share the halo in L2).  While the MFMAs of
+// (tile t, chunk c) run, the 16-byte pieces of the NEXT (tile, chunk) -- possibly the first chunk of the next tile -- are
+// already in flight into registers, so neither the first-load latency of a tile nor its epilogue stores are exposed.
+// One LDS stage; two workgroups per CU cover each other's LDS write phases.
+template <int CT, int NT, int R>
+__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
     constexpr int TH = 4 * R;
     constexpr int HALO_PIX = (TH + 2) * HALO_W;
     constexpr int HALO_ITEMS = HALO_PIX * 4;           // 16-byte slots
@@ -53,10 +201,159 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(ConvArgs a) {
     constexpr int ES = CT == TR_BF16 ? 2 : 4;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
+    constexpr int HALO_IT = (HALO_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* hl = smem;
     char* wl = smem + HALO_BYTES;
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wv = tid >> 6;
+    const int lr = l & 31, lh = l >> 5;
+    // staging plan: item it = tid + 256*j -> halo pixel pp = (tid >> 2) + 64*j, slot s = tid & 3 (constant per thread, and so
+    // is the swizzle term (pp >> 2) & 3), hence LDS offset = lds0 + 4096*j.
+    const int s_slot = tid & 3;
+    const int pp0 = tid >> 2;
+    const int lds0 = pp0 * 64 + ((s_slot ^ ((pp0 >> 2) & 3)) << 4);
+    const char* in_base = (const char*)a.in.ptr + (int64_t)(a.in.coff + s_slot * EPS) * ES;
+    const int64_t in_pix_bytes = (int64_t)a.in.cstride * ES;
+    const int ntiles = a.ntx * a.nty * a.n * a.ncg;
+
+    uint4 hreg[HALO_IT], wreg[W_IT];
+    // decode flat tile -> (cg, tx, ty, nb); cg fastest
+#define TR_DECODE(T, CG, NB, Y0, X0)                                                                                    \
+    int CG, NB, Y0, X0;                                                                                                 \
+    {                                                                                                                   \
+        int t_ = (T);                                                                                                   \
+        CG = t_ % a.ncg; t_ /= a.ncg;                                                                                    \
+        X0 = (t_ % a.ntx) * TW; t_ /= a.ntx;                                                                             \
+        Y0 = (t_ % a.nty) * TH;                                                                                          \
+        NB = t_ / a.nty;                                                                                                 \
+    }
+#define TR_ISSUE_LOADS(T, CH)                                                                                           \
+    {                                                                                                                   \
+        TR_DECODE(T, cg_, nb_, y0_, x0_)                                                                                 \
+        const bool cvalid = (((CH) * CK + s_slot * EPS) < a.cin) && !(a.dbg & 2);                                        \
+        const char* src = in_base + (int64_t)(CH) * 64 + (int64_t)nb_ * a.hin * a.win * in_pix_bytes;                    \
+        int ppb = pp0;                                                                                                  \
+        asm volatile("" : "+v"(ppb)); /* recompute the per-piece coordinates here instead of keeping them live */       \
+        _Pragma("unroll") for (int j = 0; j < HALO_IT; ++j) {                                                            \
+            const int pp = ppb + 64 * j;                                                                                 \
+            const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
+            int oy = y0_ + py - 1, ox = x0_ + px - 1;                                                                    \
+            bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);                                 \
+            if (a.replicate) {                                                                                          \
+                oy = min(max(oy, 0), a.h - 1);                                                                           \
+                ox = min(max(ox, 0), a.w - 1);                                                                           \
+                ok = pp < HALO_PIX;                                                                                      \
+            }                                                                                                           \
+            hreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (ok && cvalid) hreg[j] = *(const uint4*)(src + ((int64_t)(oy >> a.up) * a.win + (ox >> a.up)) * in_pix_bytes); \
+        }                                                                                                               \
+        const char* wsrc = a.wpacked + ((int64_t)cg_ * a.nchunks + (CH)) * (W_ITEMS * 16) + tid * 16;                    \
+        _Pragma("unroll") for (int j = 0; j < W_IT; ++j) {                                                               \
+            wreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (((W_ITEMS % NTHREADS == 0) || (tid + j * NTHREADS < W_ITEMS)) && !(a.dbg & 2))                           \
+                wreg[j] = *(const uint4*)(wsrc + j * (NTHREADS * 16));                                                   \
+        }                                                                                                               \
+    }
+
+    // Wide output groups (NT = 2) have only 2304 MFMA cycles per chunk to hide the address arithmetic of 15 pieces behind, so
+    // they keep the per-tile piece offsets in registers (12 VGPRs) and recompute only for the cross-tile prefetch.
+    constexpr bool PRE = NT == 2;
+    int64_t goff[PRE ? HALO_IT : 1];
+    unsigned hmask = 0;
+#define TR_ISSUE_LOADS_PRE(CG, CH)                                                                                      \
+    {                                                                                                                   \
+        const bool cvalid = (((CH) * CK + s_slot * EPS) < a.cin) && !(a.dbg & 2);                                        \
+        const char* src = in_base + (int64_t)(CH) * 64;                                                                  \
+        _Pragma("unroll") for (int j = 0; j < HALO_IT; ++j) {                                                            \
+            hreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (cvalid && ((hmask >> j) & 1u)) hreg[j] = *(const uint4*)(src + goff[PRE ? j : 0]);                       \
+        }                                                                                                               \
+        const char* wsrc = a.wpacked + ((int64_t)(CG) * a.nchunks + (CH)) * (W_ITEMS * 16) + tid * 16;                   \
+        _Pragma("unroll") for (int j = 0; j < W_IT; ++j) {                                                               \
+            wreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (((W_ITEMS % NTHREADS == 0) || (tid + j * NTHREADS < W_ITEMS)) && !(a.dbg & 2))                           \
+                wreg[j] = *(const uint4*)(wsrc + j * (NTHREADS * 16));                                                   \
+        }                                                                                                               \
+    }
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    TR_ISSUE_LOADS(tile, 0)
+    while (tile < ntiles) {
+        TR_DECODE(tile, cg, nb, y0, x0)
+        const bool wave_active = (y0 + wv * R) < a.h;
+        const int next_tile = tile + gridDim.x;
+        if constexpr (PRE) {
+            hmask = 0;
+#pragma unroll
+            for (int j = 0; j < HALO_IT; ++j) {
+                const int pp = pp0 + 64 * j;
+                const int py = pp / HALO_W, px = pp - py * HALO_W;
+                int oy = y0 + py - 1, ox = x0 + px - 1;
+                bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
+                if (a.replicate) {
+                    oy = min(max(oy, 0), a.h - 1);
+                    ox = min(max(ox, 0), a.w - 1);
+                    ok = pp < HALO_PIX;
+                }
+                goff[j] = ok ? (((int64_t)nb * a.hin + (oy >> a.up)) * a.win + (ox >> a.up)) * in_pix_bytes : 0;
+                hmask |= ok ? (1u << j) : 0u;
+            }
+        }
+        f32x16 acc[R][NT];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            __syncthreads();   // every wave has finished reading the previous LDS image (or the previous tile's epilogue strips)
+#pragma unroll
+            for (int j = 0; j < HALO_IT; ++j)
+                if ((HALO_ITEMS % NTHREADS == 0) || (pp0 + 64 * j < HALO_PIX)) *(uint4*)(hl + lds0 + 4096 * j) = hreg[j];
+#pragma unroll
+            for (int j = 0; j < W_IT; ++j)
+                if ((W_ITEMS % NTHREADS == 0) || (tid + j * NTHREADS < W_ITEMS)) *(uint4*)(wl + tid * 16 + j * (NTHREADS * 16)) = wreg[j];
+            __syncthreads();
+            // next pieces go in flight while this chunk's MFMAs run
+            if (ch + 1 < a.nchunks) {
+                if constexpr (PRE) TR_ISSUE_LOADS_PRE(cg, ch + 1) else TR_ISSUE_LOADS(tile, ch + 1)
+            } else if (next_tile < ntiles) TR_ISSUE_LOADS(next_tile, 0)
+            if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R>(hl, wl, acc, wv, lr, lh);
+        }
+        conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
+        tile = next_tile;
+    }
+#undef TR_ISSUE_LOADS
+#undef TR_ISSUE_LOADS_PRE
+#undef TR_DECODE
+}
+
+// ---- variant B: LDS-DMA staged (buffer_load ... lds), two LDS stages, one workgroup per CU -----------------------
+template <int CT, int NT, int R>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource / LDS-DMA builtins exist only in the device pass; the host pass needs just the stub
+    constexpr int TH = 4 * R;
+    constexpr int HALO_PIX = (TH + 2) * HALO_W;
+    constexpr int HALO_ITEMS = HALO_PIX * 4;                                 // 16-byte slots
+    constexpr int HALO_IT = (HALO_ITEMS + NTHREADS - 1) / NTHREADS;           // LDS-DMA instructions per wave (halo)
+    constexpr int HALO_BYTES = HALO_IT * NTHREADS * 16;                       // padded to whole 4 KiB rounds
+    constexpr int CGW = NT * 32;
+    constexpr int W_ITEMS = 9 * CGW * 4;
+    constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int W_BYTES = W_IT * NTHREADS * 16;
+    constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;
+    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int EPS = 16 / ES;                       // elements per slot
+    constexpr int CK = 64 / ES;                        // channels per chunk
+    constexpr unsigned OOB = 0x7fffff00u;              // beyond any num_records: the buffer load returns 0
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int l = tid & 63, wv = tid >> 6;
@@ -79,161 +376,103 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
 
-    const char* in_base = (const char*)a.in.ptr;
+    // ---- staging plan: LDS-DMA (buffer_load ... lds), two LDS stages ---------------------------------------
+    // One wave instruction lands 64 x 16 B contiguously in LDS (wave-uniform base + lane*16), so the LDS image is
+    // position-linear: position P = 256*j + tid  <->  halo pixel pp = P >> 2, stored slot s' = P & 3.  The bank swizzle
+    // therefore goes on the SOURCE: the lane fetches channel slot s = s' ^ ((pp >> 2) & 3) of that pixel (constant per
+    // thread).  Pixels outside the image (zero padding) and the tail of the last round use an out-of-range buffer
+    // offset, for which the hardware returns zeros.  The K-chunk advances through the scalar offset.
+    const int pp0 = tid >> 2;
+    const int s_src = (tid & 3) ^ ((pp0 >> 2) & 3);
     const int64_t in_pix_bytes = (int64_t)a.in.cstride * ES;
+    const char* img_base = (const char*)a.in.ptr + (int64_t)nb * a.hin * a.win * in_pix_bytes;
+    const unsigned img_bytes = (unsigned)((int64_t)a.hin * a.win * in_pix_bytes);
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img_base, 0, img_bytes, 0x00020000);
+    const char* w_cg = a.wpacked + (int64_t)cg * a.nchunks * (W_ITEMS * 16);
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_cg, 0, (unsigned)(a.nchunks * W_ITEMS * 16), 0x00020000);
+    unsigned hoff[HALO_IT];
+#pragma unroll
+    for (int j = 0; j < HALO_IT; ++j) {
+        const int pp = pp0 + 64 * j;
+        const int py = pp / HALO_W, px = pp - py * HALO_W;
+        int oy = y0 + py - 1, ox = x0 + px - 1;
+        bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
+        if (a.replicate) {
+            oy = min(max(oy, 0), a.h - 1);
+            ox = min(max(ox, 0), a.w - 1);
+            ok = pp < HALO_PIX;
+        }
+        const int sy = oy >> a.up, sx = ox >> a.up;
+        const unsigned off = (unsigned)(((int64_t)sy * a.win + sx) * in_pix_bytes + (int64_t)(a.in.coff + s_src * EPS) * ES);
+        hoff[j] = ok ? off : OOB;
+    }
+    const unsigned woff0 = (unsigned)tid * 16u;
+    const bool partial_k = (a.cin % CK) != 0;
+    if (partial_k) {
+        // channel slots past cin are never fetched (masked below): give them a defined value once
+        for (int i = tid; i < (2 * STAGE_BYTES) / 16; i += NTHREADS) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
 
+#define TR_STAGE(CH, BUF)                                                                                               \
+    {                                                                                                                   \
+        char* hb = smem + (BUF) * STAGE_BYTES + wv * 1024;                                                               \
+        const bool cvalid = !partial_k || (((CH) * CK + s_src * EPS) < a.cin);                                           \
+        if (cvalid) {                                                                                                   \
+            _Pragma("unroll") for (int j = 0; j < HALO_IT; ++j)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(hb + j * 4096), 16, \
+                                                         hoff[j], (CH) * 64, 0, 0);                                      \
+        }                                                                                                               \
+        char* wb = smem + (BUF) * STAGE_BYTES + HALO_BYTES + wv * 1024;                                                  \
+        _Pragma("unroll") for (int j = 0; j < W_IT; ++j) {                                                               \
+            if ((W_ITEMS % NTHREADS == 0) || (j * NTHREADS + wv * 64 < W_ITEMS))                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(wb + j * 4096), 16, \
+                                                         woff0 + j * 4096, (CH) * (W_ITEMS * 16), 0, 0);                 \
+        }                                                                                                               \
+    }
+
+    TR_STAGE(0, 0)
     for (int ch = 0; ch < a.nchunks; ++ch) {
-        __syncthreads();
-        // ---- stage the halo chunk --------------------------------------------------------
-        for (int it = tid; it < HALO_ITEMS; it += NTHREADS) {
-            const int pp = it >> 2, s = it & 3;
-            const int py = pp / HALO_W, px = pp - py * HALO_W;
-            int oy = y0 + py - 1, ox = x0 + px - 1;
-            bool ok = (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
-            if (a.replicate) {
-                oy = min(max(oy, 0), a.h - 1);
-                ox = min(max(ox, 0), a.w - 1);
-                ok = true;
-            }
-            const int c0 = ch * CK + s * EPS;
-            ok = ok & (c0 < a.cin);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int sy = oy >> a.up, sx = ox >> a.up;
-                const int64_t pix = ((int64_t)nb * a.hin + sy) * a.win + sx;
-                v = *(const uint4*)(in_base + pix * in_pix_bytes + (int64_t)(a.in.coff + c0) * ES);
-            }
-            *(uint4*)(hl + pp * 64 + ((s ^ ((pp >> 2) & 3)) << 4)) = v;
-        }
-        // ---- stage the weight slab (already swizzled by the packer) -----------------------
-        {
-            const char* wsrc = a.wpacked + ((int64_t)cg * a.nchunks + ch) * (W_ITEMS * 16);
-            for (int it = tid; it < W_ITEMS; it += NTHREADS)
-                *(uint4*)(wl + it * 16) = *(const uint4*)(wsrc + it * 16);
-        }
-        __syncthreads();
-        if (!wave_active) continue;
-        // ---- 9 taps x K-chunk of MFMAs ------------------------------------------------------
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int slot = q * 2 + lh;
-                if constexpr (CT == TR_BF16) {
-                    bf16x8 wa[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int row = tap * CGW + t * 32 + lr;
-                        wa[t] = *(const bf16x8*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
-                        const bf16x8 xb = *(const bf16x8*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb, acc[r][t], 0, 0, 0);
-                    }
-                } else {
-                    f32x4 wa[NT];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        const int row = tap * CGW + t * 32 + lr;
-                        wa[t] = *(const f32x4*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
-                        const f32x4 xb = *(const f32x4*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][e], xb[e], acc[r][t], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk `ch` have landed
+        __syncthreads();                                   // ... and everybody's; all waves are done reading the other stage
+        if (ch + 1 < a.nchunks) TR_STAGE(ch + 1, (ch + 1) & 1)   // in flight while this chunk's MFMAs run
+        const char* hl = smem + (ch & 1) * STAGE_BYTES;
+        if (wave_active) conv_chunk_mfma<CT, NT, R>(hl, hl + HALO_BYTES, acc, wv, lr, lh);
     }
+#undef TR_STAGE
 
-    // ---- fused epilogue -------------------------------------------------------------------------
-    const int ox = x0 + lr;
-    if (!wave_active || ox >= a.w) return;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int oy = y0 + wv * R + r;
-        if (oy >= a.h) break;
-        const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int co = cg * CGW + t * 32 + q * 8 + lh * 4;
-                if (co >= a.cout) continue;
-                const bool full = (co + 3) < a.cout;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[r][t][q * 4 + i];
-                if (a.bias) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (co + i < a.cout) v[i] += a.bias[co + i];
-                }
-                if (a.act == TR_ACT_LRELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * a.slope;
-                } else if (a.act == TR_ACT_RELU) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-                }
-                if (full) {
-                    if (a.res1.ptr) {
-                        const float4 rr = tr::view_load4(a.res1, pix, co, a.vec_res1);
-                        v[0] = v[0] * a.scale1 + a.rs1 * rr.x; v[1] = v[1] * a.scale1 + a.rs1 * rr.y;
-                        v[2] = v[2] * a.scale1 + a.rs1 * rr.z; v[3] = v[3] * a.scale1 + a.rs1 * rr.w;
-                    }
-                    if (a.res2.ptr) {
-                        const float4 rr = tr::view_load4(a.res2, pix, co, a.vec_res2);
-                        v[0] = v[0] * a.scale2 + a.rs2 * rr.x; v[1] = v[1] * a.scale2 + a.rs2 * rr.y;
-                        v[2] = v[2] * a.scale2 + a.rs2 * rr.z; v[3] = v[3] * a.scale2 + a.rs2 * rr.w;
-                    }
-                    if (a.mask.ptr) {
-                        const float4 mm = tr::view_load4(a.mask, pix, co, a.vec_mask);
-                        v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
-                        v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
-                    }
-                    tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), a.vec_out);
-                    if (a.out2.ptr) {
-                        const float s = a.out2_scale;
-                        tr::view_store4(a.out2, pix, co, make_float4(v[0] * s, v[1] * s, v[2] * s, v[3] * s), a.vec_out2);
-                    }
-                } else {
-                    for (int i = 0; i < 4 && co + i < a.cout; ++i) {
-                        float x = v[i];
-                        if (a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + i);
-                        if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + i);
-                        if (a.mask.ptr) x *= tr::view_load(a.mask, pix, co + i) > 0.f ? 1.f : a.mask_slope;
-                        tr::view_store(a.out, pix, co + i, x);
-                        if (a.out2.ptr) tr::view_store(a.out2, pix, co + i, x * a.out2_scale);
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
+#endif
 }
 
 template <int CT, int NT, int R>
-int launch(hipStream_t st, const ConvArgs& a, int ncg) {
-    constexpr int TH = 4 * R;
-    constexpr size_t lds = (size_t)(TH + 2) * HALO_W * 64 + (size_t)9 * NT * 32 * 64;
+int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
+    constexpr size_t lds = (size_t)(4 * R + 2) * HALO_W * 64 + (size_t)9 * NT * 32 * 64;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_kernel<CT, NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_kernel_reg<CT, NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    static const int persist = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 512;   // 2 per CU
+    const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
+    const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
+    hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R>), dim3(grid), dim3(NTHREADS), lds, st, a);
+    return tr::launch_status("tr_conv3x3");
+}
+
+template <int CT, int NT, int R>
+int launch_dma(hipStream_t st, const ConvArgs& a, int ncg) {
+    constexpr int halo_it = ((4 * R + 2) * HALO_W * 4 + NTHREADS - 1) / NTHREADS;
+    constexpr int w_it = (9 * NT * 32 * 4 + NTHREADS - 1) / NTHREADS;
+    constexpr size_t lds = 2 * (size_t)(halo_it + w_it) * NTHREADS * 16;
+    static_assert(lds <= 160 * 1024, "two LDS stages must fit the 160 KiB of a CU");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv3x3_kernel_dma<CT, NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((unsigned)(a.ntx * a.nty * a.n), (unsigned)ncg, 1);
-    hipLaunchKernelGGL((conv3x3_kernel<CT, NT, R>), grid, dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_kernel_dma<CT, NT, R>), grid, dim3(NTHREADS), lds, st, a);
     return tr::launch_status("tr_conv3x3");
 }
 
@@ -276,16 +515,39 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     a.wpacked = (const char*)d->wpacked; a.bias = d->bias;
     const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);
     a.nchunks = g.nchunks;
+    a.ncg = g.ncg;
     a.vec_out = tr::view_vec4_ok(d->out); a.vec_out2 = tr::view_vec4_ok(d->out2);
     a.vec_res1 = tr::view_vec4_ok(d->res1); a.vec_res2 = tr::view_vec4_ok(d->res2); a.vec_mask = tr::view_vec4_ok(d->mask);
     hipStream_t st = (hipStream_t)stream;
-    constexpr int R = 2;
+    static const int dbg = getenv("TRAINNER_CONV_DBG") ? atoi(getenv("TRAINNER_CONV_DBG")) : 0;
+    a.dbg = dbg;
     a.ntx = (d->w + TW - 1) / TW;
-    a.nty = (d->h + 4 * R - 1) / (4 * R);
-    if (d->compute == TR_BF16) {
-        if (g.cgw == 64) return launch<TR_BF16, 2, R>(st, a, g.ncg);
-        return launch<TR_BF16, 1, R>(st, a, g.ncg);
+    // Staging variant and tile height.  Measured on MI355X (profiles/): the register-staged kernel at two workgroups per
+    // CU beats the LDS-DMA kernel at one (each LDS-DMA piece costs the issuing wave 60-100 cycles and the per-CU DMA rate
+    // does not cover a 76 KB stage inside one chunk of MFMAs), so it is the default; TRAINNER_CONV_STAGING=dma selects B.
+    static const bool use_dma = getenv("TRAINNER_CONV_STAGING") && !strcmp(getenv("TRAINNER_CONV_STAGING"), "dma");
+    static const int force_r = getenv("TRAINNER_CONV_R") ? atoi(getenv("TRAINNER_CONV_R")) : 0;
+    const bool roomy = d->h >= 16 && (int64_t)d->n * ((d->h + 15) / 16) * a.ntx * g.ncg >= 512;
+    if (use_dma) {
+        TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
+                   "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
+        const bool big = force_r ? force_r == 4 : roomy;
+        a.nty = big ? (d->h + 15) / 16 : (d->h + 7) / 8;
+        if (big) {
+            if (d->compute == TR_BF16) return g.cgw == 64 ? launch_dma<TR_BF16, 2, 4>(st, a, g.ncg) : launch_dma<TR_BF16, 1, 4>(st, a, g.ncg);
+            return g.cgw == 64 ? launch_dma<TR_F32, 2, 4>(st, a, g.ncg) : launch_dma<TR_F32, 1, 4>(st, a, g.ncg);
+        }
+        if (d->compute == TR_BF16) return g.cgw == 64 ? launch_dma<TR_BF16, 2, 2>(st, a, g.ncg) : launch_dma<TR_BF16, 1, 2>(st, a, g.ncg);
+        return g.cgw == 64 ? launch_dma<TR_F32, 2, 2>(st, a, g.ncg) : launch_dma<TR_F32, 1, 2>(st, a, g.ncg);
     }
-    if (g.cgw == 64) return launch<TR_F32, 2, R>(st, a, g.ncg);
-    return launch<TR_F32, 1, R>(st, a, g.ncg);
+    // register-staged: 32-wide output groups take 16-row tiles (twice the MFMAs per staged weight slab); 64-wide groups
+    // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
+    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : roomy);
+    if (big) {
+        a.nty = (d->h + 15) / 16;
+        return d->compute == TR_BF16 ? launch_reg<TR_BF16, 1, 4>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4>(st, a, g.ncg);
+    }
+    a.nty = (d->h + 7) / 8;
+    if (d->compute == TR_BF16) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2>(st, a, g.ncg);
+    return g.cgw == 64 ? launch_reg<TR_F32, 2, 2>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2>(st, a, g.ncg);
 }
