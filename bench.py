@@ -238,8 +238,16 @@ def main():
             cnt, flops, msum = agg[key]
             peak = 2500.0 if key[0] == "bf16" else 157.3
             ach = flops / (msum * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel<{key[0]}, cout-group {key[1]}>", "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launches": cnt, "avg_launch_ms": msum / cnt,
+            traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                if tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
+                    traffic = tj[f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
+            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}>", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops / cnt, "launches": cnt,
+                               "avg_launch_ms": msum / cnt,
                                "share_of_step": msum / (dt * 1e3),
                                "all": {f"{k[0]}/cg{k[1]}": {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
         if not args.no_cpu_baseline and world == 1:

@@ -1,0 +1,39 @@
+"""Condenses rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/."""
+import csv, glob, re, sys, collections
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"\(ConvArgs\)|\(WgArgs\)", "", n)
+    return n[:80]
+
+def kernel_stats(d):
+    f = glob.glob(f"{d}/*/*kernel_stats.csv")[0]
+    rows = list(csv.DictReader(open(f)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = [f"total GPU kernel time {tot / 1e6:.1f} ms", f"{'kernel':80s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}"]
+    for r in rows[:18]:
+        out.append(f"{short(r['Name']):80s} {r['Calls']:>6s} {float(r['TotalDurationNs']) / 1e6:10.2f} {float(r['AverageNs']) / 1e3:10.1f} {float(r['Percentage']):6.2f}")
+    return "\n".join(out)
+
+def pmc(d, counter):
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    return agg
+
+if __name__ == "__main__":
+    cmd = sys.argv[1]
+    if cmd == "stats":
+        print(kernel_stats(sys.argv[2]))
+    else:
+        fe, wr = pmc(sys.argv[2], "FETCH_SIZE"), pmc(sys.argv[3], "WRITE_SIZE")
+        print(f"{'kernel':80s} {'launches':>8s} {'FETCH_SIZE/launch':>18s} {'WRITE_SIZE/launch':>18s} {'avg_us(profiled)':>16s}")
+        for k in sorted(fe, key=lambda k: -fe[k][2])[:12]:
+            w = wr.get(k, [1, 0.0, 0.0])
+            print(f"{k:80s} {fe[k][0]:8d} {fe[k][1] / fe[k][0]:18.1f} {w[1] / max(w[0], 1):18.1f} {fe[k][2] / fe[k][0]:16.1f}")
