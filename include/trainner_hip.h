@@ -38,7 +38,7 @@ enum { TR_F32 = 0, TR_BF16 = 1 };
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
 enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
-enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1 };
+enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2 };
 enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
 
 /* channel-slice view of an NHWC buffer (ptr == NULL means "absent") */
@@ -77,7 +77,9 @@ typedef struct tr_conv3x3_desc {
     int32_t n, h, w;          /* OUTPUT batch / height / width                                */
     int32_t cin, cout;
     int32_t compute;          /* TR_F32 | TR_BF16                                             */
-    int32_t in_mode;          /* TR_IN_DIRECT (input n x h x w) | TR_IN_NEAREST2X (n x h/2 x w/2) */
+    int32_t in_mode;          /* TR_IN_DIRECT (input n x h x w) | TR_IN_NEAREST2X (n x h/2 x w/2) |
+                                 TR_IN_FULL (input n x (h-2) x (w-2): 'full' correlation, out(y,x) = sum in(y+ky-2, x+kx-2) W,
+                                 i.e. the input gradient of a conv over an explicitly padded image)              */
     int32_t pad_mode;         /* TR_PAD_ZEROS | TR_PAD_REPLICATE                              */
     int32_t act;              /* TR_ACT_*                                                     */
     float   slope;            /* LeakyReLU negative slope                                     */
@@ -97,6 +99,12 @@ int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
  * normalisation, host pointer, may be NULL); dst (+)= result.  Weights are the fp32 OIHW master tensor. */
 int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_oihw, int cout, int cin, int n, int h, int w, int pad_mode,
                            const float* ch_scale_host, float* dst_nchw, int accumulate);
+
+/* Adjoint of F.pad(mode="replicate", pad=1) + NHWC->NCHW + per-channel scale, for the stem of the perceptual head
+ * (perceptual_fp16_loss.py:272-274,322): gp is the gradient w.r.t. the PADDED image, NHWC n x (h+2) x (w+2);
+ * dst[n,c,y,x] (+)= ch_scale[c] * sum of gp over every padded position that replicate-padding filled from (y,x). */
+int tr_fold_replicate_nchw(void* stream, tr_view gp, float* dst_nchw, int n, int c, int h, int w, const float* ch_scale_host,
+                           int accumulate);
 
 /* ---- weight packing -------------------------------------------------------------------------
  * Master weights stay fp32 OIHW (the state-dict layout the reference saves and spandrel loads,

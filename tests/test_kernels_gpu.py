@@ -332,3 +332,36 @@ def test_adamw_ema_clip_against_oracle(cuda):
         assert gd.abs().max().item() == 0
         assert rel_l2(p.cpu(), params["p"]) < 1e-6
         assert rel_l2(e.cpu(), ema.shadow["p"]) < 1e-6
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
+    """Input gradient of a replicate-padded 3-channel stem conv (VGG conv1_1): 'full'-mode MFMA conv on the padded domain +
+    border fold + 1/std, against autograd; and the VALU reference kernel tr_conv3x3_dgrad_image against the same."""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w, cout = 2, 14, 38, 64
+    g = torch.Generator().manual_seed(13)
+    img = torch.rand(n, 3, h, w, generator=g).requires_grad_(True)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) / 5
+    gy = torch.randn(n, cout, h, w, generator=g)
+    std = (0.229, 0.224, 0.225)
+    if compute == L.BF16:
+        wt, gy = bf(wt), bf(gy)
+    xin = img / torch.tensor(std).view(1, 3, 1, 1)
+    F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="replicate"), wt).backward(gy)
+    wd, gyd = wt.to(cuda), nhwc(gy).to(cuda, dt)
+    slab = torch.zeros(ops.packed_bytes(cout, 3, compute), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda)
+    plan.add(wd, slab, cout, 3, compute, transpose=True)
+    plan.run()
+    gp = torch.empty(n, h + 2, w + 2, 4, device=cuda)
+    ops.conv3x3(n=n, h=h + 2, w=w + 2, cin=cout, cout=3, compute=compute, inp=ops.view(gyd), out=ops.view(gp), wpacked=slab, in_mode=L.IN_FULL)
+    out = torch.full((n, 3, h, w), 2.0, device=cuda)
+    ops.fold_replicate_nchw(ops.view(gp), out, ch_scale=[1 / s for s in std], accumulate=True)
+    assert rel_l2(out.cpu() - 2.0, img.grad) < 3e-6
+    out2 = torch.empty(n, 3, h, w, device=cuda)
+    ops.conv3x3_dgrad_image(ops.view(gyd), wd, n, h, w, out2, pad_mode=L.PAD_REPLICATE, ch_scale=[1 / s for s in std])
+    assert rel_l2(out2.cpu(), img.grad) < 3e-6

@@ -15,7 +15,7 @@ ABI_VERSION = 1
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 PAD_ZEROS, PAD_REPLICATE = 0, 1
-IN_DIRECT, IN_NEAREST2X = 0, 1
+IN_DIRECT, IN_NEAREST2X, IN_FULL = 0, 1, 2
 LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
 
 
@@ -84,6 +84,7 @@ SYMBOLS = {
     "tr_conv3x3": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
     "tr_conv3x3_dgrad_image": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_int]),
+    "tr_fold_replicate_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "tr_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]),
     "tr_wgrad3x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_wgrad3x3": (C.c_int, [C.c_void_p, C.POINTER(Wgrad3x3Desc)]),

@@ -33,6 +33,7 @@ constexpr int NTHREADS = 256;
 
 struct ConvArgs {
     int n, h, w, hin, win;
+    int ih, iw, shift;   // input extent in output-resolution coordinates, and the origin shift of the 'full' mode
     int cin, cout;
     int up;            // 0/1: nearest x2 upsample fused into the load
     int replicate;
@@ -241,11 +242,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
         _Pragma("unroll") for (int j = 0; j < HALO_IT; ++j) {                                                            \
             const int pp = ppb + 64 * j;                                                                                 \
             const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
-            int oy = y0_ + py - 1, ox = x0_ + px - 1;                                                                    \
-            bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);                                 \
+            int oy = y0_ + py - 1 - a.shift, ox = x0_ + px - 1 - a.shift;                                                \
+            bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);                               \
             if (a.replicate) {                                                                                          \
-                oy = min(max(oy, 0), a.h - 1);                                                                           \
-                ox = min(max(ox, 0), a.w - 1);                                                                           \
+                oy = min(max(oy, 0), a.ih - 1);                                                                          \
+                ox = min(max(ox, 0), a.iw - 1);                                                                          \
                 ok = pp < HALO_PIX;                                                                                      \
             }                                                                                                           \
             hreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
@@ -293,11 +294,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
             for (int j = 0; j < HALO_IT; ++j) {
                 const int pp = pp0 + 64 * j;
                 const int py = pp / HALO_W, px = pp - py * HALO_W;
-                int oy = y0 + py - 1, ox = x0 + px - 1;
-                bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
+                int oy = y0 + py - 1 - a.shift, ox = x0 + px - 1 - a.shift;
+                bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);
                 if (a.replicate) {
-                    oy = min(max(oy, 0), a.h - 1);
-                    ox = min(max(ox, 0), a.w - 1);
+                    oy = min(max(oy, 0), a.ih - 1);
+                    ox = min(max(ox, 0), a.iw - 1);
                     ok = pp < HALO_PIX;
                 }
                 goff[j] = ok ? (((int64_t)nb * a.hin + (oy >> a.up)) * a.win + (ox >> a.up)) * in_pix_bytes : 0;
@@ -395,11 +396,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
     for (int j = 0; j < HALO_IT; ++j) {
         const int pp = pp0 + 64 * j;
         const int py = pp / HALO_W, px = pp - py * HALO_W;
-        int oy = y0 + py - 1, ox = x0 + px - 1;
-        bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
+        int oy = y0 + py - 1 - a.shift, ox = x0 + px - 1 - a.shift;
+        bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);
         if (a.replicate) {
-            oy = min(max(oy, 0), a.h - 1);
-            ox = min(max(ox, 0), a.w - 1);
+            oy = min(max(oy, 0), a.ih - 1);
+            ox = min(max(ox, 0), a.iw - 1);
             ok = pp < HALO_PIX;
         }
         const int sy = oy >> a.up, sx = ox >> a.up;
@@ -499,14 +500,18 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     TR_REQUIRE(view_ok(d->out, d->cout) && view_ok(d->out2, d->cout) && view_ok(d->res1, d->cout) &&
                    view_ok(d->res2, d->cout) && view_ok(d->mask, d->cout),
                TR_EINVAL, "tr_conv3x3: an epilogue view does not hold cout=%d channels", d->cout);
-    TR_REQUIRE(d->in_mode == TR_IN_DIRECT || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL,
+    TR_REQUIRE(d->in_mode != TR_IN_NEAREST2X || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL,
                "tr_conv3x3: nearest-2x input needs even output dims");
+    TR_REQUIRE(d->in_mode != TR_IN_FULL || (d->h > 2 && d->w > 2 && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL,
+               "tr_conv3x3: full mode needs output dims > 2 and zero padding");
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3: wpacked must be 16-byte aligned");
 
     ConvArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w;
     a.up = d->in_mode == TR_IN_NEAREST2X ? 1 : 0;
-    a.hin = d->h >> a.up; a.win = d->w >> a.up;
+    a.shift = d->in_mode == TR_IN_FULL ? 1 : 0;
+    a.ih = d->h - 2 * a.shift; a.iw = d->w - 2 * a.shift;
+    a.hin = a.ih >> a.up; a.win = a.iw >> a.up;
     a.cin = d->cin; a.cout = d->cout;
     a.replicate = d->pad_mode == TR_PAD_REPLICATE;
     a.act = d->act; a.slope = d->slope;

@@ -62,7 +62,46 @@ __global__ __launch_bounds__(256) void dgrad_image_kernel(tr_view gy, const floa
     }
 }
 
+__global__ __launch_bounds__(256) void fold_replicate_kernel(tr_view gp, float* __restrict__ dst, int n, int c, int h, int w, float4 chs,
+                                                             int accumulate) {
+    const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
+    const int wp = w + 2, hp = h + 2;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int nb = (int)(p / hw);
+        const int iy = (int)((p - nb * hw) / w), ix = (int)(p - nb * hw - (int64_t)iy * w);
+        // padded rows/cols that were filled from (iy, ix): itself (+1) plus the border copies
+        const int y0 = iy == 0 ? 0 : iy + 1, y1 = iy == h - 1 ? hp - 1 : iy + 1;
+        const int x0 = ix == 0 ? 0 : ix + 1, x1 = ix == w - 1 ? wp - 1 : ix + 1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const int64_t q = ((int64_t)nb * hp + y) * wp + x;
+                for (int k = 0; k < c; ++k) acc[k] += tr::view_load(gp, q, k);
+            }
+        const float sc[4] = {chs.x, chs.y, chs.z, chs.w};
+        for (int k = 0; k < c; ++k) {
+            float* o = dst + ((int64_t)nb * c + k) * hw + (int64_t)iy * w + ix;
+            const float v = acc[k] * sc[k];
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int tr_fold_replicate_nchw(void* stream, tr_view gp, float* dst_nchw, int n, int c, int h, int w, const float* ch_scale,
+                                      int accumulate) {
+    TR_REQUIRE(gp.ptr && dst_nchw && n > 0 && h > 0 && w > 0 && c >= 1 && c <= 4 && gp.c >= c, TR_EINVAL, "tr_fold_replicate_nchw: bad arguments");
+    float t[4] = {1.f, 1.f, 1.f, 1.f};
+    if (ch_scale)
+        for (int i = 0; i < c; ++i) t[i] = ch_scale[i];
+    const int64_t total = (int64_t)n * h * w;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(fold_replicate_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, gp, dst_nchw, n, c, h, w,
+                       make_float4(t[0], t[1], t[2], t[3]), accumulate);
+    return tr::launch_status("tr_fold_replicate_nchw");
+}
 
 extern "C" int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_oihw, int cout, int cin, int n, int h, int w, int pad_mode,
                                       const float* ch_scale, float* dst_nchw, int accumulate) {

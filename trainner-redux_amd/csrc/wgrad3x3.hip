@@ -37,7 +37,7 @@ struct WgArgs {
 };
 
 template <int CT, int NT>
-__global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void wgrad_kernel(WgArgs a) {
     constexpr int ES = CT == TR_BF16 ? 2 : 4;
     constexpr int EPS = 16 / ES;
     constexpr int CG = NT * 32;
@@ -76,48 +76,73 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
     const int64_t in_pix_bytes = (int64_t)a.in.cstride * ES;
     const int64_t gy_pix_bytes = (int64_t)a.gy.cstride * ES;
 
+    // staging: all 16-byte pieces of the NEXT tile are issued into registers before the current tile's MFMAs
+    // (same T14-style prefetch as conv3x3.hip), written to LDS after the barrier that ends the MFMAs.
+    constexpr int X_ITEMS = HALO_H * HALO_W * XSLOTS;
+    constexpr int G_ITEMS = TH * TW * GSLOTS;
+    constexpr int X_IT = (X_ITEMS + NTHREADS - 1) / NTHREADS;
+    constexpr int G_IT = (G_ITEMS + NTHREADS - 1) / NTHREADS;
+    uint4 xreg[X_IT], greg[G_IT];
+#define TR_WG_ISSUE(TILE)                                                                                               \
+    {                                                                                                                   \
+        int t_ = (TILE);                                                                                                \
+        const int x0_ = (t_ % a.ntx) * TW; t_ /= a.ntx;                                                                  \
+        const int y0_ = (t_ % a.nty) * TH;                                                                               \
+        const int nb_ = t_ / a.nty;                                                                                      \
+        int tb = tid;                                                                                                   \
+        asm volatile("" : "+v"(tb)); /* recompute piece coordinates here instead of keeping them live */                \
+        _Pragma("unroll") for (int j = 0; j < X_IT; ++j) {                                                               \
+            const int it = tb + j * NTHREADS;                                                                            \
+            const int pp = it / XSLOTS, s_ = it - pp * XSLOTS;                                                           \
+            const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
+            int oy = y0_ + py - 1, ox = x0_ + px - 1;                                                                    \
+            bool ok = (it < X_ITEMS) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);                                  \
+            if (a.replicate) {                                                                                          \
+                oy = min(max(oy, 0), a.h - 1);                                                                           \
+                ox = min(max(ox, 0), a.w - 1);                                                                           \
+                ok = it < X_ITEMS;                                                                                       \
+            }                                                                                                           \
+            const int c0 = chunk * CKW + s_ * EPS;                                                                       \
+            ok = ok & (c0 + EPS <= a.in.c);                                                                              \
+            xreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (ok) xreg[j] = *(const uint4*)(in_base + (((int64_t)nb_ * a.hin + (oy >> a.up)) * a.win + (ox >> a.up)) * in_pix_bytes + \
+                                              (int64_t)(a.in.coff + c0) * ES);                                           \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < G_IT; ++j) {                                                               \
+            const int it = tb + j * NTHREADS;                                                                            \
+            const int gp = it / GSLOTS, s_ = it - gp * GSLOTS;                                                           \
+            const int oy = y0_ + (gp >> 5), ox = x0_ + (gp & 31);                                                        \
+            const int c0 = cg * CG + s_ * EPS;                                                                           \
+            const bool ok = (it < G_ITEMS) & (oy < a.h) & (ox < a.w) & (c0 + EPS <= a.gy.c);                             \
+            greg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (ok) greg[j] = *(const uint4*)(gy_base + (((int64_t)nb_ * a.h + oy) * a.w + ox) * gy_pix_bytes +          \
+                                              (int64_t)(a.gy.coff + c0) * ES);                                           \
+        }                                                                                                               \
+    }
+
+    if (slot < a.ntiles) TR_WG_ISSUE(slot)
     for (int tile = slot; tile < a.ntiles; tile += a.nslots) {
-        int t = tile;
-        const int tx = t % a.ntx; t /= a.ntx;
-        const int ty = t % a.nty;
-        const int nb = t / a.nty;
-        const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();
-        for (int it = tid; it < HALO_H * HALO_W * XSLOTS; it += NTHREADS) {
-            const int pp = it / XSLOTS, s = it - pp * XSLOTS;
-            const int py = pp / HALO_W, px = pp - py * HALO_W;
-            int oy = y0 + py - 1, ox = x0 + px - 1;
-            bool ok = (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);
-            if (a.replicate) {
-                oy = min(max(oy, 0), a.h - 1);
-                ox = min(max(ox, 0), a.w - 1);
-                ok = true;
+        __syncthreads();   // previous tile's fragments have all been read
+#pragma unroll
+        for (int j = 0; j < X_IT; ++j) {
+            const int it = tid + j * NTHREADS;
+            if (it < X_ITEMS) {
+                const int pp = it / XSLOTS, s_ = it - pp * XSLOTS;
+                *(uint4*)(xl + pp * XPIX_BYTES + s_ * 16) = xreg[j];
             }
-            const int c0 = chunk * CKW + s * EPS;
-            ok = ok & (c0 + EPS <= a.in.c);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t pix = ((int64_t)nb * a.hin + (oy >> a.up)) * a.win + (ox >> a.up);
-                v = *(const uint4*)(in_base + pix * in_pix_bytes + (int64_t)(a.in.coff + c0) * ES);
-            }
-            *(uint4*)(xl + pp * XPIX_BYTES + s * 16) = v;
         }
-        for (int it = tid; it < TH * TW * GSLOTS; it += NTHREADS) {
-            const int gp = it / GSLOTS, s = it - gp * GSLOTS;
-            const int py = gp >> 5, px = gp & 31;
-            const int oy = y0 + py, ox = x0 + px;
-            const int c0 = cg * CG + s * EPS;
-            const bool ok = (oy < a.h) & (ox < a.w) & (c0 + EPS <= a.gy.c);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
-                v = *(const uint4*)(gy_base + pix * gy_pix_bytes + (int64_t)(a.gy.coff + c0) * ES);
+#pragma unroll
+        for (int j = 0; j < G_IT; ++j) {
+            const int it = tid + j * NTHREADS;
+            if (it < G_ITEMS) {
+                const int gp = it / GSLOTS, s_ = it - gp * GSLOTS;
+                int so = s_ * 16;
+                if (GSWZ) so ^= ((gp >> 1) & 1) << 6;
+                *(uint4*)(gl + gp * GPIX_BYTES + so) = greg[j];
             }
-            int so = s * 16;
-            if (GSWZ) so ^= ((gp >> 1) & 1) << 6;
-            *(uint4*)(gl + gp * GPIX_BYTES + so) = v;
         }
         __syncthreads();
+        if (tile + a.nslots < a.ntiles) TR_WG_ISSUE(tile + a.nslots)   // in flight during this tile's MFMAs
 
         if constexpr (CT == TR_BF16) {
             const int li = l & 15, q = li >> 2, p = li & 3;
@@ -194,6 +219,7 @@ __global__ __launch_bounds__(NTHREADS) void wgrad_kernel(WgArgs a) {
             if (lh == 0) a.db_partials[((int64_t)slot * a.ncg + cg) * CG + t2 * 32 + lr] = v;
         }
     }
+#undef TR_WG_ISSUE
     // partial block: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
     float* dst = a.partials + (((int64_t)slot * a.nchunks + chunk) * a.ncg + cg) * (CG * 9 * CKW);
 #pragma unroll

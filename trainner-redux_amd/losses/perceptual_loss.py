@@ -179,10 +179,9 @@ class VGG(nn.Module):
             cin_f = 8 if k == 0 else m.cin
             f = torch.zeros(ops.packed_bytes(cin_f, m.cout, cd), dtype=torch.uint8, device=dev)
             plan.add(m.weight.data, f, cin_f, m.cout, cd)
-            b = None
-            if k > 0:
-                b = torch.zeros(ops.packed_bytes(m.cout, m.cin, cd), dtype=torch.uint8, device=dev)
-                plan.add(m.weight.data, b, m.cout, m.cin, cd, transpose=True)
+            # transposed / flipped slab of the input-gradient conv (for conv1_1: 64 -> 3 channels on the padded domain)
+            b = torch.zeros(ops.packed_bytes(m.cout, m.cin, cd), dtype=torch.uint8, device=dev)
+            plan.add(m.weight.data, b, m.cout, m.cin, cd, transpose=True)
             pk[name] = (f, b)
         plan.finalize().run()
         self._packs = ((cd, str(dev)), pk, plan)
@@ -209,6 +208,7 @@ class VGG(nn.Module):
                 ws["acts"].append(e(n, hh, ww, ws["acts"][-1].shape[-1]))
         # gradient ping-pong per resolution level
         ws["g"] = {k: [e(n, k[0], k[1], c), e(n, k[0], k[1], c)] for k, c in levels.items()}
+        ws["gp"] = torch.empty(n, h + 2, w + 2, 4, dtype=torch.float32, device=dev)   # gradient w.r.t. the replicate-padded image
         self._ws[key] = ws
         return ws
 
@@ -306,8 +306,11 @@ class VGG(nn.Module):
             if grad is None:
                 continue
             if k == 0:
-                ops.conv3x3_dgrad_image(V(g), m.weight.data, n, hh, ww, grad, pad_mode=L.PAD_REPLICATE,
-                                        ch_scale=[1.0 / s for s in IMAGENET_STD], accumulate=not first)
+                # conv1_1 ran on a replicate-padded image: its input gradient is the 'full' correlation on the padded domain
+                # (MFMA conv, 64 -> 3 channels), folded back onto the image border, scaled by 1/std, added into NCHW grad
+                ops.conv3x3(n=n, h=hh + 2, w=ww + 2, cin=m.cout, cout=m.cin, compute=cd, inp=V(g), out=V(ws["gp"]), wpacked=pk[name][1],
+                            in_mode=L.IN_FULL)
+                ops.fold_replicate_nchw(V(ws["gp"]), grad, ch_scale=[1.0 / s for s in IMAGENET_STD], accumulate=not first)
                 break
             # gradient w.r.t. this conv's input = transposed conv of g; the input came through a fused ReLU unless it is a pool output
             prev = prog[k - 1]

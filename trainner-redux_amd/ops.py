@@ -162,6 +162,13 @@ def conv3x3_dgrad_image(gy: L.View, w_oihw: torch.Tensor, n, h, w, dst: torch.Te
                                            1 if accumulate else 0), "tr_conv3x3_dgrad_image")
 
 
+def fold_replicate_nchw(gp: L.View, dst: torch.Tensor, ch_scale=None, accumulate=False):
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 4
+    n, c, h, w = dst.shape
+    sc = (C.c_float * c)(*[float(v) for v in ch_scale]) if ch_scale is not None else None
+    L.check(L.lib().tr_fold_replicate_nchw(stream_ptr(), gp, dst.data_ptr(), n, c, h, w, sc, 1 if accumulate else 0), "tr_fold_replicate_nchw")
+
+
 def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int):
     L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix), "tr_axpby")
 
