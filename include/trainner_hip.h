@@ -40,6 +40,7 @@ enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
 enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2 };
 enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
+enum { TR_GAN_VANILLA = 0, TR_GAN_LSGAN = 1, TR_GAN_WGAN = 2, TR_GAN_WGAN_SOFTPLUS = 3, TR_GAN_HINGE = 4 };
 
 /* channel-slice view of an NHWC buffer (ptr == NULL means "absent") */
 typedef struct tr_view {
@@ -161,9 +162,9 @@ int tr_nhwc_to_nchw(void* stream, tr_view src, float* dst, int n, int c_dst, int
 /* gradient of tr_nchw_to_nhwc wrt src: dst_nchw[c] = g[c] / std[c] */
 int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w,
                            const float* inv_std3, int accumulate);
-/* out = (out.dtype)(a*sa + b*sb) for NHWC views of equal shape (b optional) -- residual adds of the
- * gradient streams and dtype conversion */
-int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix);
+/* out = (out.dtype)((a*sa + b*sb) * (mask > 0 ? 1 : mask_slope)) for NHWC views of equal shape (b and mask optional) --
+ * residual / skip adds of activations and gradient streams, dtype conversion, LeakyReLU derivative of a skip branch */
+int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope);
 /* adjoint of nn.Upsample(scale_factor=2, mode="nearest") (scunet_aaf6aa_arch.py:371): 2x2 sum pooling,
  * optionally times the LeakyReLU derivative taken from `mask` (the saved activation at low resolution) */
 int tr_sumpool2x2(void* stream, tr_view in, tr_view out, tr_view mask, float mask_slope, int n, int h_in, int w_in);
@@ -202,6 +203,42 @@ typedef struct tr_pixel_loss_desc {
     float*  partials;         /* >= 1024 floats of scratch                   */
 } tr_pixel_loss_desc;
 int tr_pixel_loss(void* stream, const tr_pixel_loss_desc* d);
+
+/* ---- U-Net discriminator pieces (archs/discriminator_arch.py:98-160) ---------------------------------------------------
+ * 4x4 stride-2 pad-1 convs run as space-to-depth(2) + the 3x3 MFMA conv on expanded weights:
+ *   s2d: out[n, y/2, x/2, ((y&1)*2 + (x&1))*C + c] = in[n, y, x, c]          (h, w = full-resolution dims, even)
+ *   w3[co][(dy,dx,ci)][ky][kx] = w4[co][ci][2ky+dy-1][2kx+dx-1] or 0        (tr_expand_w4x4s2 / adjoint tr_collapse_g3x3s2d) */
+int tr_space_to_depth2(void* stream, tr_view in, tr_view out, int n, int h, int w);
+int tr_depth_to_space2(void* stream, tr_view in, tr_view out, int n, int h, int w);
+int tr_expand_w4x4s2(void* stream, const float* w4_oihw, float* w3_oihw, int cout, int cin);
+int tr_collapse_g3x3s2d(void* stream, const float* g3_oihw, float* g4_oihw, int cout, int cin, int accumulate);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) (:139,144,149) and its adjoint */
+int tr_bilinear_up2x(void* stream, tr_view in, tr_view out, int n, int h_in, int w_in);
+int tr_bilinear_up2x_bwd(void* stream, tr_view gout, tr_view gin, int n, int h_in, int w_in);
+/* torch.nn.utils.spectral_norm, old-style hook (:115-128): W is rows x cols (= cout x cin*kh*kw); with power_iteration != 0
+ * v <- normalize(W^T u), u <- normalize(W v) in place (eps 1e-12), then sigma = u^T W v, w_out = W / sigma.
+ * scratch: rows + cols floats.  Backward: g_worig += (G - <G, W/sigma> u v^T) / sigma; scratch: 256 floats. */
+int tr_spectral_norm(void* stream, const float* w_orig, float* u, float* v, float* w_out, float* sigma_out, int rows, int cols,
+                     int power_iteration, float eps, float* scratch);
+int tr_spectral_norm_bwd(void* stream, const float* g_wsn, const float* w_sn, const float* u, const float* v, const float* sigma,
+                         float* g_worig, int rows, int cols, float* scratch);
+
+/* ---- GAN loss head (losses/gan_loss.py:13-126), mean over fp32 logits; same value / total / grad contract as tr_pixel_loss */
+typedef struct tr_gan_loss_desc {
+    int32_t gan_type;         /* TR_GAN_*                                    */
+    int32_t target_is_real;
+    int32_t is_disc;
+    int32_t reserved;
+    const float* logits;
+    int64_t numel;
+    float   real_label, fake_label;
+    float   value_weight, total_weight, grad_weight;
+    float*  value_out;
+    float*  total_out;        /* or NULL                                     */
+    float*  grad;             /* numel floats or NULL: d(grad_weight*loss)/dlogits (overwritten) */
+    float*  partials;         /* >= 1024 floats                              */
+} tr_gan_loss_desc;
+int tr_gan_loss(void* stream, const tr_gan_loss_desc* d);
 
 /* ---- optimizer sweep --------------------------------------------------------------------------
  * torch.optim.AdamW (optimizers/__init__.py:30-47, templates: lr 2e-4, betas (0.9, 0.99), wd 0)

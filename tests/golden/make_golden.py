@@ -10,6 +10,8 @@ Fixtures
                         (vanilla, lsgan, hinge, wgan, wgan_softplus x real/fake x is_disc)
   registry.pt           registry key behaviour (lower-casing, suffix fallback, duplicate assertion)
   sampler.pt            data_sampler.EnlargedSampler index streams (epoch-seeded permutation, rank stride)
+  unet_discriminator_sn.pt  discriminator_arch.UNetDiscriminatorSN(num_feat=16): weights/u/v before and after one training-mode
+                        forward, output, input- and parameter-gradients, eval-mode output
 """
 import importlib.util
 import os
@@ -110,6 +112,24 @@ def main():
                 out[f"{world}/{rank}/{epoch}"] = torch.tensor(list(iter(s)))
             out[f"{world}/{rank}/len"] = len(s)
     torch.save(out, os.path.join(OUT, "sampler.pt"))
+    # ---- UNetDiscriminatorSN (discriminator_arch.py:98-160): training-mode forward (one power iteration) + backward -------
+    da = _load("traiNNer.archs.discriminator_arch", "traiNNer/archs/discriminator_arch.py")
+    _stub("traiNNer.archs")
+    torch.manual_seed(77)
+    net = da.UNetDiscriminatorSN(num_in_ch=3, num_feat=16, skip_connection=True)
+    net.train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    x = torch.rand(2, 3, 32, 48).requires_grad_(True)
+    y = net(x)
+    wsum = torch.randn(y.shape)
+    (y * wsum).sum().backward()
+    fix = {"state_before": sd0, "x": x.detach(), "y": y.detach(), "gy": wsum, "gx": x.grad.clone(),
+           "state_after": {k: v.clone() for k, v in net.state_dict().items()},
+           "grads": {k: p.grad.clone() for k, p in net.named_parameters()}}
+    net.eval()
+    with torch.no_grad():
+        fix["y_eval"] = net(x.detach())
+    torch.save(fix, os.path.join(OUT, "unet_discriminator_sn.pt"))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".pt")))
 
 

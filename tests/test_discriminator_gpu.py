@@ -1,0 +1,128 @@
+"""UNetDiscriminatorSN + GANLoss on HIP against the REFERENCE's own tensors (tests/golden/*.pt, produced by running
+/root/reference/traiNNer/archs/discriminator_arch.py and losses/gan_loss.py in the build container)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def test_gan_loss_matches_reference_golden(cuda):
+    from trainner_redux_amd.losses import build_loss
+
+    fix = torch.load(os.path.join(GOLD, "pixel_gan_losses.pt"), weights_only=True)
+    logits = fix["logits"].to(cuda)
+    for key, ref in fix["gan"].items():
+        gt_, real, disc = key.split("/")
+        loss = build_loss(dict(type="ganloss", loss_weight=0.1, gan_type=gt_))
+        x = logits.clone().requires_grad_(True)
+        v = loss(x, bool(int(real)), is_disc=bool(int(disc)))
+        assert abs(v.item() - ref.item()) <= 2e-6 * max(abs(ref.item()), 1e-3), (key, v.item(), ref.item())
+        v.backward()
+        xr = fix["logits"].clone().requires_grad_(True)
+        from oracle import losses as OL
+        OL.gan(xr, bool(int(real)), is_disc=bool(int(disc)), gan_type=gt_).backward()
+        assert rel_l2(x.grad.cpu(), xr.grad) < 2e-6, key
+
+
+def test_small_kernels_of_the_discriminator(cuda):
+    from torch.nn import functional as F
+
+    from trainner_redux_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 8, 12, 20, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    # bilinear x2 and its adjoint
+    up = torch.empty(2, 24, 40, 8, device=cuda)
+    ops.bilinear_up2x(ops.view(xd), ops.view(up), 2, 12, 20)
+    xr = x.clone().requires_grad_(True)
+    ref = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+    assert rel_l2(up.permute(0, 3, 1, 2).cpu(), ref.detach()) < 1e-6
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(cuda)
+    gx = torch.empty_like(xd)
+    ops.bilinear_up2x_bwd(ops.view(gyd), ops.view(gx), 2, 12, 20)
+    assert rel_l2(gx.permute(0, 3, 1, 2).cpu(), xr.grad) < 1e-6
+    # space-to-depth round trip and the 4x4-stride-2 == 3x3-over-s2d identity
+    s = torch.empty(2, 6, 10, 32, device=cuda)
+    ops.space_to_depth2(ops.view(xd), ops.view(s), 2, 12, 20)
+    back = torch.empty_like(xd)
+    ops.depth_to_space2(ops.view(s), ops.view(back), 2, 12, 20)
+    assert torch.equal(back, xd)
+    w4 = torch.randn(16, 8, 4, 4, generator=g)
+    w3 = torch.empty(16, 32, 3, 3, device=cuda)
+    w4d = w4.to(cuda)
+    ops.expand_w4x4s2(w4d, w3)
+    ref4 = F.conv2d(x, w4, None, stride=2, padding=1)
+    got = F.conv2d(s.permute(0, 3, 1, 2).cpu(), w3.cpu(), None, padding=1)
+    assert rel_l2(got, ref4) < 1e-6
+    g3 = torch.randn(16, 32, 3, 3, generator=g).to(cuda)
+    g4 = torch.empty(16, 8, 4, 4, device=cuda)
+    ops.collapse_g3x3s2d(g3, g4)
+    # adjoint identity: <expand(w4), g3> == <w4, collapse(g3)>
+    assert abs((w3 * g3).sum().item() - (w4d * g4).sum().item()) < 1e-3
+    # spectral norm forward / backward against autograd
+    from oracle import discriminator as OD
+
+    w = torch.randn(24, 10, 3, 3, generator=g)
+    u = F.normalize(torch.randn(24, generator=g), dim=0)
+    v = F.normalize(torch.randn(90, generator=g), dim=0)
+    wr = w.clone().requires_grad_(True)
+    wsn, u2, v2 = OD.spectral_weight(wr, u, v, training=True)
+    G = torch.randn(wsn.shape, generator=g)
+    (wsn * G).sum().backward()
+    wd, ud, vd = w.to(cuda), u.to(cuda), v.to(cuda)
+    out, sig = torch.empty_like(wd), torch.zeros(1, device=cuda)
+    ops.spectral_norm(wd, ud, vd, out, sig, power_iteration=True)
+    assert rel_l2(out.cpu(), wsn.detach()) < 1e-6 and rel_l2(ud.cpu(), u2) < 1e-6 and rel_l2(vd.cpu(), v2) < 1e-6
+    gw = torch.zeros_like(wd)
+    Gd = G.to(cuda)
+    ops.spectral_norm_bwd(Gd, out, ud, vd, sig, gw)
+    assert rel_l2(gw.cpu(), wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("compute", [torch.float32, torch.bfloat16])
+def test_unet_discriminator_matches_reference_golden(cuda, compute):
+    from trainner_redux_amd.archs import build_network
+
+    fix = torch.load(os.path.join(GOLD, "unet_discriminator_sn.pt"), weights_only=True)
+    net = build_network(dict(type="unetdiscriminatorsn", num_in_ch=3, num_feat=16, skip_connection=True))
+    assert list(net.state_dict().keys()) == list(fix["state_before"].keys())
+    net.load_state_dict(fix["state_before"])
+    net = net.to(cuda)
+    net.compute_dtype = compute
+    net.train()
+    x = fix["x"].to(cuda)
+    y = net.forward_hip(x, train=True)
+    tol = 2e-5 if compute == torch.float32 else 2e-2
+    assert rel_l2(y.cpu(), fix["y"]) < tol, rel_l2(y.cpu(), fix["y"])
+    sd = net.state_dict()
+    for k in fix["state_after"]:
+        if k.endswith(("weight_u", "weight_v")):   # the power iteration ran in fp32 in both
+            assert rel_l2(sd[k].cpu(), fix["state_after"][k]) < 1e-5, k
+    gx = torch.zeros(2, 3, 32, 48, device=cuda)
+    net.backward_hip(fix["gy"].to(cuda), param_grads=True, input_grad=gx, input_grad_accumulate=False)
+    # bf16 here is compared with the fp32 reference itself (not a same-policy oracle): activations, skip sums and gradient
+    # operands are all bf16 in this net, and the weight gradients of the deepest layers collect that noise (measured 0.06-0.09)
+    gtol = 2e-4 if compute == torch.float32 else 0.15
+    assert rel_l2(gx.cpu(), fix["gx"]) < gtol, rel_l2(gx.cpu(), fix["gx"])
+    worst = max((rel_l2(p.grad.cpu(), fix["grads"][k]), k) for k, p in net.named_parameters())
+    print(compute, "fwd", rel_l2(y.cpu(), fix["y"]), "gx", rel_l2(gx.cpu(), fix["gx"]), "worst param grad", worst)
+    assert worst[0] < gtol, worst
+    if compute == torch.float32:
+        net.eval()
+        ye = net.forward_hip(x, train=False)
+        assert rel_l2(ye.cpu(), fix["y_eval"]) < 2e-5
+        # autograd bridge: stock-torch loss on top, gradient to the image
+        net.train()
+        xi = x.clone().requires_grad_(True)
+        net(xi).mean().backward()
+        assert xi.grad is not None and torch.isfinite(xi.grad).all() and xi.grad.abs().sum() > 0

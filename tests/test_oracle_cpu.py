@@ -118,3 +118,26 @@ def test_bf16_policy_sits_closer_to_fp32_than_autocast():
             ya = OE.forward(sd, x, hp).float()
     rel = lambda a: ((a - y).norm() / y.norm()).item()  # noqa: E731
     assert rel(yb) < rel(ya) < 5e-2
+
+
+def test_discriminator_oracle_matches_reference_golden():
+    """oracle/discriminator.py vs the reference module's own tensors (UNetDiscriminatorSN, num_feat 16)."""
+    from oracle import discriminator as OD
+
+    fix = torch.load(os.path.join(GOLD, "unet_discriminator_sn.pt"), weights_only=True)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and ("weight_orig" in k or k.startswith(("conv0", "conv9"))) else v.clone())
+          for k, v in fix["state_before"].items()}
+    x = fix["x"].clone().requires_grad_(True)
+    y, uv = OD.forward(sd, x, training=True)
+    assert torch.allclose(y, fix["y"], rtol=1e-5, atol=1e-6)
+    (y * fix["gy"]).sum().backward()
+    assert torch.allclose(x.grad, fix["gx"], rtol=1e-4, atol=1e-6)
+    for k, g in fix["grads"].items():
+        assert torch.allclose(sd[k].grad, g, rtol=1e-4, atol=1e-6), k
+    for name, (u, v) in uv.items():
+        assert torch.allclose(u, fix["state_after"][f"{name}.weight_u"], atol=1e-6)
+        assert torch.allclose(v, fix["state_after"][f"{name}.weight_v"], atol=1e-6)
+    sd_after = {k: v for k, v in fix["state_after"].items()}
+    with torch.no_grad():
+        ye, _ = OD.forward(sd_after, fix["x"], training=False)
+    assert torch.allclose(ye, fix["y_eval"], rtol=1e-5, atol=1e-6)

@@ -17,6 +17,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 IN_DIRECT, IN_NEAREST2X, IN_FULL = 0, 1, 2
 LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
+GAN_TYPES = {"vanilla": 0, "lsgan": 1, "wgan": 2, "wgan_softplus": 3, "hinge": 4}
 
 
 class View(C.Structure):
@@ -66,6 +67,15 @@ class PixelLossDesc(C.Structure):
     ]
 
 
+class GanLossDesc(C.Structure):
+    _fields_ = [
+        ("gan_type", C.c_int32), ("target_is_real", C.c_int32), ("is_disc", C.c_int32), ("reserved", C.c_int32),
+        ("logits", C.c_void_p), ("numel", C.c_int64),
+        ("real_label", C.c_float), ("fake_label", C.c_float), ("value_weight", C.c_float), ("total_weight", C.c_float), ("grad_weight", C.c_float),
+        ("value_out", C.c_void_p), ("total_out", C.c_void_p), ("grad", C.c_void_p), ("partials", C.c_void_p),
+    ]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [
         ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
@@ -91,7 +101,16 @@ SYMBOLS = {
     "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_nhwc_to_nchw_scaled": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
-    "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64]),
+    "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64, View, C.c_float]),
+    "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
+    "tr_depth_to_space2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
+    "tr_expand_w4x4s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tr_collapse_g3x3s2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tr_bilinear_up2x": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
+    "tr_bilinear_up2x_bwd": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
+    "tr_spectral_norm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "tr_spectral_norm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tr_gan_loss": (C.c_int, [C.c_void_p, C.POINTER(GanLossDesc)]),
     "tr_sumpool2x2": (C.c_int, [C.c_void_p, View, View, View, C.c_float, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),

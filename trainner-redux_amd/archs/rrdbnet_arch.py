@@ -29,6 +29,7 @@ from torch import nn
 from .. import _lib as L
 from .. import ops
 from ..utils.registry import SPANDREL_REGISTRY
+from ._arena import FlatParamModule
 
 SLOPE = 0.2
 RES = 0.2
@@ -78,7 +79,7 @@ class _Workspace:
     pass
 
 
-class RRDBNet(nn.Module):
+class RRDBNet(FlatParamModule):
     hyperparameters: dict
 
     def __init__(self, *, in_nc=3, out_nc=3, num_filters=64, num_blocks=23, scale=4, shuffle_factor=None, gc=32) -> None:
@@ -102,70 +103,7 @@ class RRDBNet(nn.Module):
         self._idx_hr, self._idx_last = idx, idx + 2
         self.model = _Seq(items)
         self.compute_dtype = torch.bfloat16
-        self._arena = None
-        self._grad_arena = None
-        self._plan = None
-        self._ws: dict = {}
-        self._saved = None
-        self._trigger = None
-
-    # ------------------------------------------------------------------ parameter arena ------------
-    def _convs(self) -> list[_Conv]:
-        return [m for m in self.modules() if isinstance(m, _Conv)]
-
-    def _flatten(self) -> None:
-        ps = list(self.parameters())
-        dev = ps[0].device
-        offs, total = [], 0
-        for p in ps:
-            offs.append(total)
-            total += (p.numel() + 3) // 4 * 4
-        arena = torch.zeros(total, dtype=torch.float32, device=dev)
-        garena = torch.zeros(total, dtype=torch.float32, device=dev)
-        for p, o in zip(ps, offs):
-            if p.dtype != torch.float32:
-                raise TypeError("master weights stay float32; select bf16 compute with `compute_dtype`")
-            arena[o:o + p.numel()].copy_(p.data.reshape(-1))
-            if p.grad is not None:
-                garena[o:o + p.numel()].copy_(p.grad.reshape(-1))
-            p.data = arena[o:o + p.numel()].view(p.shape)
-            p.grad = garena[o:o + p.numel()].view(p.shape) if p.requires_grad else None
-        self._arena, self._grad_arena, self._offsets = arena, garena, offs
-        self._plan = None
-        self._ws = {}
-
-    def __deepcopy__(self, memo):
-        # an EMA twin must not inherit workspaces, saved activations or slabs that alias the online net
-        cls = self.__class__
-        new = cls.__new__(cls)
-        memo[id(self)] = new
-        import copy as _copy
-        for k, v in self.__dict__.items():
-            if k in ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets"):
-                continue
-            new.__dict__[k] = _copy.deepcopy(v, memo)
-        new._ws, new._saved, new._plan, new._trigger, new._arena, new._grad_arena = {}, None, None, None, None, None
-        return new
-
-    def _apply(self, fn, recurse=True):
-        out = super()._apply(fn, recurse)
-        self._arena = None  # storage moved: rebuild lazily
-        return out
-
-    def _ensure_arena(self) -> None:
-        ps = list(self.parameters())
-        if self._arena is None or ps[0].data_ptr() != self._arena.data_ptr() or ps[0].device != self._arena.device:
-            self._flatten()
-        elif ps[0].requires_grad and (ps[0].grad is None or ps[-1].grad is None or ps[0].grad.data_ptr() != self._grad_arena.data_ptr()):
-            # optimizer.zero_grad(set_to_none=True) dropped the views: re-attach, zeroed
-            self._grad_arena.zero_()
-            for p, o in zip(ps, self._offsets):
-                p.grad = self._grad_arena[o:o + p.numel()].view(p.shape)
-
-    def flat_parameters(self) -> tuple[torch.Tensor, torch.Tensor]:
-        """(params arena, grads arena) -- consumed by the fused AdamW/EMA sweep."""
-        self._ensure_arena()
-        return self._arena, self._grad_arena
+        self._init_arena_state()
 
     # ------------------------------------------------------------------ weight packing --------------
     def _cd(self) -> int:

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tr_view src, float* _
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, int c4, int va,
-                                                     int vb, int vout) {
+                                                     int vb, int vout, tr_view mask, float mslope, int vm) {
     const int64_t total = npix * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / c4;
@@ -52,6 +52,11 @@ __global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view
         if (b.ptr) {
             const float4 w = tr::view_load4(b, p, c, vb);
             v.x += sb * w.x; v.y += sb * w.y; v.z += sb * w.z; v.w += sb * w.w;
+        }
+        if (mask.ptr) {
+            const float4 m = tr::view_load4(mask, p, c, vm);
+            v.x *= m.x > 0.f ? 1.f : mslope; v.y *= m.y > 0.f ? 1.f : mslope;
+            v.z *= m.z > 0.f ? 1.f : mslope; v.w *= m.w > 0.f ? 1.f : mslope;
         }
         tr::view_store4(out, p, c, v, vout);
     }
@@ -178,11 +183,11 @@ extern "C" int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int
     return tr::launch_status("tr_nhwc_to_nchw_scaled");
 }
 
-extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix) {
-    TR_REQUIRE(a.ptr && out.ptr && npix > 0 && a.c == out.c && a.c % 4 == 0 && (!b.ptr || b.c == a.c), TR_EINVAL,
+extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope) {
+    TR_REQUIRE(a.ptr && out.ptr && npix > 0 && a.c == out.c && a.c % 4 == 0 && (!b.ptr || b.c == a.c) && (!mask.ptr || mask.c == a.c), TR_EINVAL,
                "tr_axpby: views must have equal channel counts that are multiples of 4");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (a.c / 4))), dim3(256), 0, (hipStream_t)stream, a, sa, b, sb, out, npix, a.c / 4,
-                       (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out));
+                       (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out), mask, mask_slope, (int)tr::view_vec4_ok(mask));
     return tr::launch_status("tr_axpby");
 }
 

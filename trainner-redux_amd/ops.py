@@ -169,8 +169,69 @@ def fold_replicate_nchw(gp: L.View, dst: torch.Tensor, ch_scale=None, accumulate
     L.check(L.lib().tr_fold_replicate_nchw(stream_ptr(), gp, dst.data_ptr(), n, c, h, w, sc, 1 if accumulate else 0), "tr_fold_replicate_nchw")
 
 
-def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int):
-    L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix), "tr_axpby")
+def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, mask: L.View | None = None, mask_slope: float = 0.2):
+    L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix, mask if mask is not None else NULL_VIEW, mask_slope), "tr_axpby")
+
+
+def space_to_depth2(inp: L.View, out: L.View, n, h, w):
+    L.check(L.lib().tr_space_to_depth2(stream_ptr(), inp, out, n, h, w), "tr_space_to_depth2")
+
+
+def depth_to_space2(inp: L.View, out: L.View, n, h, w):
+    L.check(L.lib().tr_depth_to_space2(stream_ptr(), inp, out, n, h, w), "tr_depth_to_space2")
+
+
+def expand_w4x4s2(w4: torch.Tensor, w3: torch.Tensor):
+    cout, cin = w4.shape[0], w4.shape[1]
+    assert w4.shape[2:] == (4, 4) and w3.shape == (cout, 4 * cin, 3, 3) and w4.is_contiguous() and w3.is_contiguous()
+    L.check(L.lib().tr_expand_w4x4s2(stream_ptr(), w4.data_ptr(), w3.data_ptr(), cout, cin), "tr_expand_w4x4s2")
+
+
+def collapse_g3x3s2d(g3: torch.Tensor, g4: torch.Tensor, accumulate=False):
+    cout, cin = g4.shape[0], g4.shape[1]
+    assert g4.shape[2:] == (4, 4) and g3.shape == (cout, 4 * cin, 3, 3) and g3.is_contiguous() and g4.is_contiguous()
+    L.check(L.lib().tr_collapse_g3x3s2d(stream_ptr(), g3.data_ptr(), g4.data_ptr(), cout, cin, 1 if accumulate else 0), "tr_collapse_g3x3s2d")
+
+
+def bilinear_up2x(inp: L.View, out: L.View, n, h_in, w_in):
+    L.check(L.lib().tr_bilinear_up2x(stream_ptr(), inp, out, n, h_in, w_in), "tr_bilinear_up2x")
+
+
+def bilinear_up2x_bwd(gout: L.View, gin: L.View, n, h_in, w_in):
+    L.check(L.lib().tr_bilinear_up2x_bwd(stream_ptr(), gout, gin, n, h_in, w_in), "tr_bilinear_up2x_bwd")
+
+
+def spectral_norm(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, w_out: torch.Tensor, sigma: torch.Tensor, power_iteration: bool,
+                  eps: float = 1e-12):
+    rows = w_orig.shape[0]
+    cols = w_orig.numel() // rows
+    assert u.numel() == rows and v.numel() == cols and w_out.numel() == w_orig.numel() and w_orig.is_contiguous()
+    L.check(L.lib().tr_spectral_norm(stream_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(), w_out.data_ptr(), sigma.data_ptr(), rows, cols,
+                                     1 if power_iteration else 0, eps, scratch(w_orig.device, rows + cols + 64).data_ptr()), "tr_spectral_norm")
+
+
+def spectral_norm_bwd(g_wsn: torch.Tensor, w_sn: torch.Tensor, u, v, sigma, g_worig: torch.Tensor):
+    rows = w_sn.shape[0]
+    cols = w_sn.numel() // rows
+    assert g_wsn.numel() == w_sn.numel() == g_worig.numel() and g_worig.is_contiguous()
+    L.check(L.lib().tr_spectral_norm_bwd(stream_ptr(), g_wsn.data_ptr(), w_sn.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
+                                         g_worig.data_ptr(), rows, cols, scratch(w_sn.device).data_ptr()), "tr_spectral_norm_bwd")
+
+
+def gan_loss(gan_type: str, logits: torch.Tensor, target_is_real: bool, is_disc: bool, value_out: torch.Tensor, *, value_weight=1.0,
+             total_out=None, total_weight=0.0, grad: torch.Tensor | None = None, grad_weight=1.0, real_label=1.0, fake_label=0.0):
+    _need_cuda(logits, value_out, grad, total_out)
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    d = L.GanLossDesc()
+    d.gan_type, d.target_is_real, d.is_disc = L.GAN_TYPES[gan_type], int(bool(target_is_real)), int(bool(is_disc))
+    d.logits, d.numel = logits.data_ptr(), logits.numel()
+    d.real_label, d.fake_label = real_label, fake_label
+    d.value_weight, d.total_weight, d.grad_weight = value_weight, total_weight, grad_weight
+    d.value_out = value_out.data_ptr()
+    d.total_out = total_out.data_ptr() if total_out is not None else None
+    d.grad = grad.data_ptr() if grad is not None else None
+    d.partials = scratch(logits.device).data_ptr()
+    L.check(L.lib().tr_gan_loss(stream_ptr(), C.byref(d)), "tr_gan_loss")
 
 
 def sumpool2x2(inp: L.View, out: L.View, mask: L.View, mask_slope: float, n, h_in, w_in):
