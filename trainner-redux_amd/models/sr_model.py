@@ -94,6 +94,8 @@ class SRModel:
             if self.opt.network_d is None:
                 raise ValueError("GAN loss requires discriminator network (network_d)")
             self.net_d = build_network(self.opt.network_d).to(self.device)
+            if hasattr(self.net_d, "compute_dtype"):
+                self.net_d.compute_dtype = self.compute_dtype
             if self.opt.path.pretrain_network_d is not None:
                 self.load_network(self.net_d, self.opt.path.pretrain_network_d, self.opt.path.strict_load_d, self.opt.path.param_key_d)
 
@@ -119,6 +121,8 @@ class SRModel:
             self.net_g_ema.initted = self.net_g_ema.initted.cpu()
             if hasattr(self.net_g_ema.ema_model, "compute_dtype"):
                 self.net_g_ema.ema_model.compute_dtype = self.compute_dtype
+        if train_opt.adaptive_d:
+            raise NotImplementedError("adaptive_d (sr_model.py:558-569) is not on the HIP path yet")
         self.grad_clip = train_opt.grad_clip
         self.grad_clip_threshold = 1.0   # get_automation_clipping_threshold() default without automations
         if train_opt.losses is None:
@@ -150,6 +154,8 @@ class SRModel:
         self.optimizers.append(self.optimizer_g)
         self.optimizers_skipped.append(False)
         if self.net_d is not None and train_opt.optim_d is not None:
+            if hasattr(self.net_d, "flat_parameters"):
+                self.net_d.flat_parameters()
             self.optimizer_d = build_optimizer(list(self.net_d.parameters()), train_opt.optim_d)
             self.optimizers.append(self.optimizer_d)
             self.optimizers_skipped.append(False)
@@ -229,7 +235,7 @@ class SRModel:
     # ------------------------------------------------------------------ THE HOT PATH ---------------------------
     def optimize_parameters(self, current_iter: int, current_accum_iter: int, apply_gradient: bool) -> None:
         assert self.lq is not None and self.gt is not None
-        if self.net_d is not None:
+        if self.net_d is not None and not hasattr(self.net_d, "forward_hip"):
             for p in self.net_d.parameters():
                 p.requires_grad = False
         n_samples = self.gt.shape[0]
@@ -264,7 +270,16 @@ class SRModel:
             if loss.loss_weight < 0:
                 raise NotImplementedError("negative loss_weight (bicubic-LQ target, sr_model.py:503-516) is not on the HIP path yet")
             slot = len(keys)
-            if hasattr(loss, "hip_value_and_grad") and label != "l_g_gan":
+            if label == "l_g_gan" and hasattr(loss, "hip_value_and_grad") and hasattr(self.net_d, "forward_hip"):
+                # generator-side GAN term, all on HIP: D(output) -> loss(pred, real) -> dL/dlogits -> D backward to the image only
+                logits = self.net_d.forward_hip(self.output, train=True)
+                g_logits = torch.empty_like(logits)
+                loss.hip_value_and_grad(logits, True, False, value_weight=w, value_out=scal[slot:], total_weight=w / acc, total_out=total,
+                                        grad_weight=w / acc, grad=g_logits)
+                self.net_d.backward_hip(g_logits, param_grads=False, input_grad=gout, input_grad_accumulate=not first)
+                keys.append(label)
+                first = False
+            elif hasattr(loss, "hip_value_and_grad") and label != "l_g_gan":
                 # fused head.  scalar head: total += loss*w/acc ; dict head: total += v*w*acc  (sr_model.py:654-663)
                 is_dict = getattr(loss, "returns_dict", False)
                 k = float(acc) if is_dict else 1.0 / acc
@@ -362,37 +377,68 @@ class SRModel:
                     self.net_g_ema.update()
             self.optimizers_skipped[0] = False
 
-        # ---- discriminator update (sr_model.py:725-808); stock-PyTorch D on the open plugin surface -------------
+        # ---- discriminator update (sr_model.py:725-808) ------------------------------------------------------------------
         cri_gan = self.losses.get("l_g_gan")
         if self.net_d is not None and cri_gan is not None and self.optimizer_d is not None and not skip_d_update:
-            for p in self.net_d.parameters():
-                p.requires_grad = True
-            with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
-                real_d_pred = self.net_d(gt)
-                fake_d_pred = self.net_d(self.output.detach())
-                l_d_real = cri_gan(real_d_pred, True, is_disc=True)
-                l_d_fake = cri_gan(fake_d_pred, False, is_disc=True)
-                l_d_total = (l_d_real + l_d_fake) * cri_gan.loss_weight
-            (l_d_total / acc).backward()
-            scal[LD_REAL] = l_d_real.detach().float()
-            scal[LD_FAKE] = l_d_fake.detach().float()
-            keys += ["l_d_real", "l_d_fake"]
-            idx += [LD_REAL, LD_FAKE]
-            if apply_gradient:
-                if world > 1:
-                    for p in self.net_d.parameters():
-                        if p.grad is not None:
-                            torch.distributed.all_reduce(p.grad)
-                            p.grad.div_(world)
-                gn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad, 2) for p in self.net_d.parameters()
-                                                           if p.grad is not None]))
-                scal[GN_D] = gn
-                keys.append("grad_norm_d")
-                idx.append(GN_D)
-                if self.grad_clip:
-                    torch.nn.utils.clip_grad_norm_(self.net_d.parameters(), self.grad_clip_threshold)
-                self.optimizer_d.step()
-                self.optimizer_d.zero_grad()
+            wd = cri_gan.loss_weight   # the reference scales the D loss by the G-side weight (sr_model.py:763-768)
+            if hasattr(self.net_d, "forward_hip") and hasattr(cri_gan, "hip_value_and_grad"):
+                dnet = self.net_d
+                for img, is_real, slot_ in ((gt, True, LD_REAL), (self.output, False, LD_FAKE)):
+                    logits = dnet.forward_hip(img, train=True)
+                    g_logits = torch.empty_like(logits)
+                    cri_gan.hip_value_and_grad(logits, is_real, True, value_weight=1.0, value_out=scal[slot_:], grad_weight=wd / acc,
+                                               grad=g_logits)
+                    dnet.backward_hip(g_logits, param_grads=True)
+                keys += ["l_d_real", "l_d_fake"]
+                idx += [LD_REAL, LD_FAKE]
+                if apply_gradient:
+                    parr_d, garr_d = dnet.flat_parameters()
+                    if world > 1:
+                        allreduce_flat_(garr_d)
+                        gv = garr_d.view(-1, 4)
+                        ops.axpby(ops.view(gv), 1.0 / world, ops.NULL_VIEW, 0.0, ops.view(gv), gv.shape[0])
+                    ops.sumsq_norm(garr_d, scal[GN_D:GN_D + 1])
+                    keys.append("grad_norm_d")
+                    idx.append(GN_D)
+                    if isinstance(self.optimizer_d, AdamW):
+                        self.optimizer_d.set_step_extras(clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=scal[GN_D:GN_D + 1])
+                        self.optimizer_d.step()
+                    else:
+                        if self.grad_clip:
+                            torch.nn.utils.clip_grad_norm_(dnet.parameters(), self.grad_clip_threshold)
+                        self.optimizer_d.step()
+                        garr_d.zero_()
+            else:   # stock-PyTorch discriminator from the open plugin surface: ordinary autograd
+                for p in self.net_d.parameters():
+                    p.requires_grad = True
+                with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
+                    real_d_pred = self.net_d(gt)
+                    fake_d_pred = self.net_d(self.output.detach())
+                    l_d_real = cri_gan(real_d_pred, True, is_disc=True)
+                    l_d_fake = cri_gan(fake_d_pred, False, is_disc=True)
+                    l_d_total = (l_d_real + l_d_fake) * wd
+                (l_d_total / acc).backward()
+                scal[LD_REAL] = l_d_real.detach().float()
+                scal[LD_FAKE] = l_d_fake.detach().float()
+                keys += ["l_d_real", "l_d_fake"]
+                idx += [LD_REAL, LD_FAKE]
+                if apply_gradient:
+                    if world > 1:
+                        for p in self.net_d.parameters():
+                            if p.grad is not None:
+                                torch.distributed.all_reduce(p.grad)
+                                p.grad.div_(world)
+                    gn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad, 2) for p in self.net_d.parameters()
+                                                               if p.grad is not None]))
+                    scal[GN_D] = gn
+                    keys.append("grad_norm_d")
+                    idx.append(GN_D)
+                    if self.grad_clip:
+                        torch.nn.utils.clip_grad_norm_(self.net_d.parameters(), self.grad_clip_threshold)
+                    self.optimizer_d.step()
+                    self.optimizer_d.zero_grad()
+            if apply_gradient and len(self.optimizers_skipped) > 1:
+                self.optimizers_skipped[-1] = False
 
         # device-resident log values of this step; read back lazily by get_current_log()
         self._pending.append((keys, scal[idx], n_samples))
