@@ -36,7 +36,7 @@ extern "C" {
 
 enum { TR_F32 = 0, TR_BF16 = 1 };
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
-enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2 };
+enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
 enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2 };
 enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
@@ -55,6 +55,8 @@ int         tr_abi_version(void);
 const char* tr_last_error(void);
 /* number of bytes of packed weights for a (cin, cout) 3x3 conv in `compute` dtype */
 size_t      tr_conv3x3_packed_bytes(int cin, int cout, int compute);
+/* same for a ksize x ksize kernel (ksize = 1: token GEMMs, i.e. nn.Linear over an NHWC token grid) */
+size_t      tr_conv_packed_bytes(int cin, int cout, int compute, int ksize);
 
 /* ---- 3x3 stride-1 pad-1 convolution as implicit GEMM on MFMA ------------------------------
  * Replaces torch.nn.Conv2d(k=3,s=1,p=1) + the pointwise ops the reference applies around it:
@@ -91,6 +93,11 @@ typedef struct tr_conv3x3_desc {
     tr_view in, out, out2, res1, res2, mask;
     const void*  wpacked;     /* from tr_pack_conv3x3 (layout documented in DESIGN.md)        */
     const float* bias;        /* cout floats or NULL                                          */
+    int32_t ksize;            /* 3 (3x3, pad 1) or 1 (1x1: nn.Linear over tokens laid out as an n x h x w grid,
+                                 traiNNer/archs/drct_arch.py:64-66,166-168)                     */
+    int32_t mask_mode;        /* 0: LeakyReLU/ReLU derivative by sign ; 1: exact-GELU derivative of `mask`   */
+    const float* sample_scale;/* optional n floats multiplied into v per image before res1 (DropPath keep mask,
+                                 drct_arch.py:572-573); with act = TR_ACT_GELU, out2 receives the pre-activation */
 } tr_conv3x3_desc;
 
 int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
@@ -124,6 +131,8 @@ typedef struct tr_pack_seg {
     int32_t dst_o_off, dst_i_off;   /* in the packed conv's (cout, cin) index space           */
     int32_t transpose;
     int32_t compute;          /* TR_F32 | TR_BF16                                             */
+    int32_t ksize;            /* 3 or 1: src is OI(ksize)(ksize)                              */
+    int32_t reserved;
     int64_t first;            /* exclusive prefix sum of o_cnt*i_cnt*9 over segments (host-filled) */
 } tr_pack_seg;
 
@@ -146,9 +155,12 @@ typedef struct tr_wgrad3x3_desc {
     float*  db;               /* cout or NULL                                                 */
     float*  partials;
     size_t  partials_bytes;
+    int32_t ksize;            /* 3 or 1 (dw is then cout x cin, the nn.Linear weight gradient) */
+    int32_t reserved;
 } tr_wgrad3x3_desc;
 
 size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout);
+size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize);
 int    tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d);
 
 /* ---- layout / pointwise ----------------------------------------------------------------------

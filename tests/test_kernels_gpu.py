@@ -365,3 +365,80 @@ def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
     out2 = torch.empty(n, 3, h, w, device=cuda)
     ops.conv3x3_dgrad_image(ops.view(gyd), wd, n, h, w, out2, pad_mode=L.PAD_REPLICATE, ch_scale=[1 / s for s in std])
     assert rel_l2(out2.cpu(), img.grad) < 3e-6
+
+
+@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180)])
+def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
+    """nn.Linear over tokens (drct_arch.py:64-66,166-168) = the MFMA kernel with ksize 1 on an n x h x 32 token grid:
+    forward with exact GELU (+ pre-activation side output), input gradient with the GELU-derivative mask, weight/bias gradient."""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute = L.F32 if compute_name == "f32" else L.BF16
+    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    n, h, w, kp, nout = dims            # kp: padded input width (multiple of 32), k = kp - 12 real inputs
+    k = kp - 12 if kp > 64 else kp - 4
+    g = torch.Generator().manual_seed(kp + nout)
+    x = torch.randn(n * h * w, k, generator=g)
+    wt = torch.randn(nout, k, generator=g) / math.sqrt(k)
+    b = torch.randn(nout, generator=g)
+    keep = torch.tensor([1.25, 0.0][:n])
+    if compute == L.BF16:
+        x, wt = bf(x), bf(wt)
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    pre = F.linear(xr, wr, br)
+    y = F.gelu(pre) * keep.repeat_interleave(h * w).view(-1, 1)
+    gy = torch.randn(y.shape, generator=g)
+    if compute == L.BF16:
+        gy = bf(gy)
+    y.backward(gy)
+    xd = torch.zeros(n, h, w, kp, dtype=dt, device=cuda)
+    xd[..., :k] = x.view(n, h, w, k).to(cuda, dt)
+    nop = (nout + 31) // 32 * 32
+    wd, bd, keepd = wt.to(cuda), b.to(cuda), keep.to(cuda)
+    slab = torch.zeros(ops.packed_bytes(kp, nout, compute, 1), dtype=torch.uint8, device=cuda)
+    slab_t = torch.zeros(ops.packed_bytes(nop, k, compute, 1), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda)
+    plan.add(wd, slab, kp, nout, compute)
+    plan.add(wd, slab_t, nop, k, compute, transpose=True)
+    plan.run()
+    out = torch.zeros(n, h, w, nop, dtype=torch.float32, device=cuda)
+    pre_d = torch.zeros(n, h, w, nop, dtype=dt, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=kp, cout=nout, compute=compute, inp=ops.view(xd), out=ops.view(out), out2=ops.view(pre_d), wpacked=slab, bias=bd,
+                act=L.ACT_GELU, ksize=1, sample_scale=keepd)
+    assert rel_l2(out[..., :nout].reshape(-1, nout).cpu(), y.detach()) < 3e-6
+    assert out[..., nout:].abs().max().item() == 0
+    tolp = 3e-6 if compute == L.F32 else 3e-3
+    assert rel_l2(pre_d[..., :nout].float().reshape(-1, nout).cpu(), pre.detach()) < tolp
+    # input gradient: dX = (gy * keep * gelu'(pre)) @ W ; the mask/keep are applied by a preceding axpby-like op in the net, here on the host
+    gpre = (gy * keep.repeat_interleave(h * w).view(-1, 1) * torch.autograd.grad(F.gelu(pre.detach().requires_grad_(True)).sum(),
+                                                                                  [])[0] if False else None)
+    pre_det = pre.detach().clone().requires_grad_(True)
+    F.gelu(pre_det).sum().backward()
+    gpre = gy * keep.repeat_interleave(h * w).view(-1, 1) * pre_det.grad
+    if compute == L.BF16:
+        gpre = bf(gpre)
+    gpd = torch.zeros(n, h, w, nop, dtype=dt, device=cuda)
+    gpd[..., :nout] = gpre.view(n, h, w, nout).to(cuda, dt)
+    gx = torch.zeros(n, h, w, kp, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=nop, cout=k, compute=compute, inp=ops.view(gpd), out=ops.view(gx), wpacked=slab_t, ksize=1)
+    ref_gx = gpre @ wt
+    assert rel_l2(gx[..., :k].reshape(-1, k).cpu(), ref_gx) < 3e-6
+    # weight / bias gradient
+    ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, k, nout, 1) // 4 + 16, dtype=torch.float32, device=cuda)
+    dw = torch.full((nout, k), 3.0, device=cuda)
+    db = torch.full((nout,), 3.0, device=cuda)
+    ops.wgrad3x3(n=n, h=h, w=w, cin=k, cout=nout, compute=compute, inp=ops.view(xd), gy=ops.view(gpd), dw=dw, db=db, workspace=ws, ksize=1)
+    assert rel_l2(dw.cpu(), gpre.t() @ x) < 5e-6
+    assert rel_l2(db.cpu(), gpre.sum(0)) < 5e-6
+    # GELU-derivative mask in the epilogue (mask_mode 1): gx2 = (gy @ W2^T-like) * gelu'(mask)
+    mk = torch.randn(n, h, w, kp, generator=g)
+    mkd = mk.to(cuda, dt)
+    gx2 = torch.zeros_like(gx)
+    ops.conv3x3(n=n, h=h, w=w, cin=nop, cout=k, compute=compute, inp=ops.view(gpd), out=ops.view(gx2), wpacked=slab_t, ksize=1,
+                mask=ops.view(mkd, 0, kp), mask_mode=1)
+    mref = mkd.float().cpu()[..., :k].reshape(-1, k).requires_grad_(True)
+    F.gelu(mref).sum().backward()
+    assert rel_l2(gx2[..., :k].reshape(-1, k).cpu(), ref_gx * mref.grad) < 3e-6

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 IN_DIRECT, IN_NEAREST2X, IN_FULL = 0, 1, 2
 LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
@@ -33,6 +33,7 @@ class Conv3x3Desc(C.Structure):
         ("mask_slope", C.c_float), ("out2_scale", C.c_float),
         ("inp", View), ("out", View), ("out2", View), ("res1", View), ("res2", View), ("mask", View),
         ("wpacked", C.c_void_p), ("bias", C.c_void_p),
+        ("ksize", C.c_int32), ("mask_mode", C.c_int32), ("sample_scale", C.c_void_p),
     ]
 
 
@@ -43,7 +44,7 @@ class PackSeg(C.Structure):
         ("o_off", C.c_int32), ("o_cnt", C.c_int32), ("i_off", C.c_int32), ("i_cnt", C.c_int32),
         ("dst_cin", C.c_int32), ("dst_cout", C.c_int32),
         ("dst_o_off", C.c_int32), ("dst_i_off", C.c_int32),
-        ("transpose", C.c_int32), ("compute", C.c_int32),
+        ("transpose", C.c_int32), ("compute", C.c_int32), ("ksize", C.c_int32), ("reserved", C.c_int32),
         ("first", C.c_int64),
     ]
 
@@ -55,6 +56,7 @@ class Wgrad3x3Desc(C.Structure):
         ("compute", C.c_int32), ("in_mode", C.c_int32), ("pad_mode", C.c_int32), ("accumulate", C.c_int32),
         ("inp", View), ("gy", View),
         ("dw", C.c_void_p), ("db", C.c_void_p), ("partials", C.c_void_p), ("partials_bytes", C.c_size_t),
+        ("ksize", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -91,12 +93,14 @@ SYMBOLS = {
     "tr_abi_version": (C.c_int, []),
     "tr_last_error": (C.c_char_p, []),
     "tr_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "tr_conv_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_conv3x3": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
     "tr_conv3x3_dgrad_image": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_int]),
     "tr_fold_replicate_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "tr_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]),
     "tr_wgrad3x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_wgrad3x3": (C.c_int, [C.c_void_p, C.POINTER(Wgrad3x3Desc)]),
     "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -18,3 +18,7 @@ extern "C" size_t tr_conv3x3_packed_bytes(int cin, int cout, int compute) {
     tr::PackGeom g = tr::pack_geom(cin, cout, compute);
     return (size_t)g.ncg * g.nchunks * 9 * g.cgw * 64;
 }
+extern "C" size_t tr_conv_packed_bytes(int cin, int cout, int compute, int ksize) {
+    tr::PackGeom g = tr::pack_geom(cin, cout, compute);
+    return (size_t)g.ncg * g.nchunks * ksize * ksize * g.cgw * 64;
+}

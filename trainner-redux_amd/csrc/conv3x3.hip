@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TW = 32;        // pixels along x per MFMA tile
-constexpr int HALO_W = TW + 2;
+constexpr int HALO_W = TW + 2;   // 3x3 kernels (the LDS-DMA variant is 3x3 only)
 constexpr int NTHREADS = 256;
 
 struct ConvArgs {
@@ -39,6 +39,8 @@ struct ConvArgs {
     int replicate;
     int act;
     float slope, scale1, scale2, rs1, rs2, mask_slope, out2_scale;
+    int mask_mode;                 // 0: multiply by (m > 0 ? 1 : mask_slope) ; 1: multiply by gelu'(m)
+    const float* sample_scale;     // optional n floats: v *= sample_scale[image] before the first residual (DropPath keep mask)
     tr_view in, out, out2, res1, res2, mask;
     const char* wpacked;
     const float* bias;
@@ -49,12 +51,13 @@ struct ConvArgs {
 
 
 // ---- 9 taps x one K-chunk of MFMAs out of the staged LDS image (hl: halo, wl: weight slab) --------------------------
-template <int CT, int NT, int R>
+template <int CT, int NT, int R, int KS = 3>
 __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int wv, int lr, int lh) {
     constexpr int CGW = NT * 32;
+    constexpr int HALO_W = TW + KS - 1;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
+    for (int tap = 0; tap < KS * KS; ++tap) {
+        const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int slot = q * 2 + lh;
@@ -94,6 +97,11 @@ __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, 
         }
         __builtin_amdgcn_sched_barrier(0);   // bound the live operand fragments to one tap (VGPR budget)
     }
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {   // d/dx [x * Phi(x)], exact (erf) GELU like nn.GELU()
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
 // ---- fused epilogue: bias, activation, two scaled residuals, derivative mask, dual-dtype NHWC stores ------------------
@@ -149,6 +157,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
             }
+            float pre[4] = {v[0], v[1], v[2], v[3]};   // value before GELU: what out2 stores in GELU mode (needed by the backward)
+            if (a.act == TR_ACT_GELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+            }
+            if (a.sample_scale) {
+                const float ss = a.sample_scale[nb];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= ss;
+            }
             if (full && !generic) {
                 if (a.res1.ptr) {
                     const float4 rr = tr::view_load4(a.res1, pix, co, true);
@@ -162,22 +180,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                 }
                 if (a.mask.ptr) {
                     const float4 mm = tr::view_load4(a.mask, pix, co, true);
-                    v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
-                    v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
+                    if (a.mask_mode == 1) {
+                        v[0] *= gelu_grad(mm.x); v[1] *= gelu_grad(mm.y); v[2] *= gelu_grad(mm.z); v[3] *= gelu_grad(mm.w);
+                    } else {
+                        v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
+                        v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
+                    }
                 }
                 tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), true);
                 if (a.out2.ptr) {
                     const float sc = a.out2_scale;
-                    tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
+                    if (a.act == TR_ACT_GELU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
+                    else tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
                 }
             } else {
                 for (int k = 0; k < 4 && co + k < a.cout; ++k) {
                     float x = v[k];
                     if (a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + k);
                     if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
-                    if (a.mask.ptr) x *= tr::view_load(a.mask, pix, co + k) > 0.f ? 1.f : a.mask_slope;
+                    if (a.mask.ptr) {
+                        const float m = tr::view_load(a.mask, pix, co + k);
+                        x *= a.mask_mode == 1 ? gelu_grad(m) : (m > 0.f ? 1.f : a.mask_slope);
+                    }
                     tr::view_store(a.out, pix, co + k, x);
-                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, x * a.out2_scale);
+                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, a.act == TR_ACT_GELU ? pre[k] : x * a.out2_scale);
                 }
             }
         }
@@ -191,14 +217,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // (tile t, chunk c) run, the 16-byte pieces of the NEXT (tile, chunk) -- possibly the first chunk of the next tile -- are
 // already in flight into registers, so neither the first-load latency of a tile nor its epilogue stores are exposed.
 // One LDS stage; two workgroups per CU cover each other's LDS write phases.
-template <int CT, int NT, int R>
+template <int CT, int NT, int R, int KS>
 __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
     constexpr int TH = 4 * R;
-    constexpr int HALO_PIX = (TH + 2) * HALO_W;
+    constexpr int PAD = KS / 2;                        // KS = 3: 3x3 pad 1 ; KS = 1: 1x1 (token GEMMs: Linear layers)
+    constexpr int HALO_W = TW + KS - 1;
+    constexpr int HALO_PIX = (TH + KS - 1) * HALO_W;
     constexpr int HALO_ITEMS = HALO_PIX * 4;           // 16-byte slots
     constexpr int HALO_BYTES = HALO_PIX * 64;
     constexpr int CGW = NT * 32;
-    constexpr int W_ITEMS = 9 * CGW * 4;
+    constexpr int W_ITEMS = KS * KS * CGW * 4;
     constexpr int ES = CT == TR_BF16 ? 2 : 4;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
         _Pragma("unroll") for (int j = 0; j < HALO_IT; ++j) {                                                            \
             const int pp = ppb + 64 * j;                                                                                 \
             const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
-            int oy = y0_ + py - 1 - a.shift, ox = x0_ + px - 1 - a.shift;                                                \
+            int oy = y0_ + py - PAD - a.shift, ox = x0_ + px - PAD - a.shift;                                                \
             bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);                               \
             if (a.replicate) {                                                                                          \
                 oy = min(max(oy, 0), a.ih - 1);                                                                          \
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
             for (int j = 0; j < HALO_IT; ++j) {
                 const int pp = pp0 + 64 * j;
                 const int py = pp / HALO_W, px = pp - py * HALO_W;
-                int oy = y0 + py - 1 - a.shift, ox = x0 + px - 1 - a.shift;
+                int oy = y0 + py - PAD - a.shift, ox = x0 + px - PAD - a.shift;
                 bool ok = (pp < HALO_PIX) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);
                 if (a.replicate) {
                     oy = min(max(oy, 0), a.ih - 1);
@@ -325,7 +353,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
             if (ch + 1 < a.nchunks) {
                 if constexpr (PRE) TR_ISSUE_LOADS_PRE(cg, ch + 1) else TR_ISSUE_LOADS(tile, ch + 1)
             } else if (next_tile < ntiles) TR_ISSUE_LOADS(next_tile, 0)
-            if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R>(hl, wl, acc, wv, lr, lh);
+            if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R, KS>(hl, wl, acc, wv, lr, lh);
         }
         conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
         tile = next_tile;
@@ -446,18 +474,20 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
 #endif
 }
 
-template <int CT, int NT, int R>
+template <int CT, int NT, int R, int KS>
 int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
-    constexpr size_t lds = (size_t)(4 * R + 2) * HALO_W * 64 + (size_t)9 * NT * 32 * 64;
+    constexpr size_t stage = (size_t)(4 * R + KS - 1) * (TW + KS - 1) * 64 + (size_t)KS * KS * NT * 32 * 64;
+    constexpr size_t strips = (size_t)4 * 32 * (NT * 32 * 4 + 16);          // epilogue transposition strips
+    constexpr size_t lds = stage > strips ? stage : strips;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv3x3_kernel_reg<CT, NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)conv3x3_kernel_reg<CT, NT, R, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     static const int persist = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 512;   // 2 per CU
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
     const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
-    hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R>), dim3(grid), dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R, KS>), dim3(grid), dim3(NTHREADS), lds, st, a);
     return tr::launch_status("tr_conv3x3");
 }
 
@@ -518,7 +548,8 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     a.scale1 = d->scale1; a.scale2 = d->scale2; a.rs1 = d->res1_scale; a.rs2 = d->res2_scale; a.mask_slope = d->mask_slope; a.out2_scale = d->out2_scale;
     a.in = d->in; a.out = d->out; a.out2 = d->out2; a.res1 = d->res1; a.res2 = d->res2; a.mask = d->mask;
     a.wpacked = (const char*)d->wpacked; a.bias = d->bias;
-    const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);
+    a.mask_mode = d->mask_mode; a.sample_scale = d->sample_scale;
+    const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);   // geometry is per tap; ksize only scales the slab
     a.nchunks = g.nchunks;
     a.ncg = g.ncg;
     a.vec_out = tr::view_vec4_ok(d->out); a.vec_out2 = tr::view_vec4_ok(d->out2);
@@ -533,7 +564,9 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     static const bool use_dma = getenv("TRAINNER_CONV_STAGING") && !strcmp(getenv("TRAINNER_CONV_STAGING"), "dma");
     static const int force_r = getenv("TRAINNER_CONV_R") ? atoi(getenv("TRAINNER_CONV_R")) : 0;
     const bool roomy = d->h >= 16 && (int64_t)d->n * ((d->h + 15) / 16) * a.ntx * g.ncg >= 512;
-    if (use_dma) {
+    TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_conv3x3: ksize must be 3 or 1 (got %d)", d->ksize);
+    TR_REQUIRE(d->ksize == 3 || (d->in_mode == TR_IN_DIRECT && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct input");
+    if (use_dma && d->ksize == 3) {
         TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
                    "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
         const bool big = force_r ? force_r == 4 : roomy;
@@ -548,11 +581,21 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     // register-staged: 32-wide output groups take 16-row tiles (twice the MFMAs per staged weight slab); 64-wide groups
     // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
     const bool big = g.cgw == 32 && (force_r ? force_r == 4 : roomy);
+    const bool bf = d->compute == TR_BF16;
+    if (d->ksize == 1) {
+        if (big) {
+            a.nty = (d->h + 15) / 16;
+            return bf ? launch_reg<TR_BF16, 1, 4, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 1>(st, a, g.ncg);
+        }
+        a.nty = (d->h + 7) / 8;
+        if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 1>(st, a, g.ncg);
+        return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 1>(st, a, g.ncg);
+    }
     if (big) {
         a.nty = (d->h + 15) / 16;
-        return d->compute == TR_BF16 ? launch_reg<TR_BF16, 1, 4>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4>(st, a, g.ncg);
+        return bf ? launch_reg<TR_BF16, 1, 4, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 3>(st, a, g.ncg);
     }
     a.nty = (d->h + 7) / 8;
-    if (d->compute == TR_BF16) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2>(st, a, g.ncg);
-    return g.cgw == 64 ? launch_reg<TR_F32, 2, 2>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2>(st, a, g.ncg);
+    if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 3>(st, a, g.ncg);
+    return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 3>(st, a, g.ncg);
 }

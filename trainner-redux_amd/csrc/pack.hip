@@ -24,20 +24,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const tr_pack_seg* __restrict
             if (segs[mid].first <= i) lo = mid; else hi = mid - 1;
         }
         const tr_pack_seg s = segs[lo];
+        const int kk = s.ksize == 1 ? 1 : 9;
         int64_t r = i - s.first;
-        const int tap = (int)(r % 9); r /= 9;
+        const int tap = (int)(r % kk); r /= kk;
         const int ii = (int)(r % s.i_cnt);
         const int oo = (int)(r / s.i_cnt);
-        const float val = s.src[((int64_t)(s.o_off + oo) * s.src_i + (s.i_off + ii)) * 9 + tap];
+        const float val = s.src[((int64_t)(s.o_off + oo) * s.src_i + (s.i_off + ii)) * kk + tap];
         const int co = s.dst_o_off + (s.transpose ? ii : oo);
         const int ci = s.dst_i_off + (s.transpose ? oo : ii);
-        const int tp = s.transpose ? 8 - tap : tap;
+        const int tp = s.transpose ? kk - 1 - tap : tap;
         const tr::PackGeom g = tr::pack_geom(s.dst_cin, s.dst_cout, s.compute);
         const int cg = co / g.cgw, col = co - cg * g.cgw;
         const int chunk = ci / g.ck, cil = ci - chunk * g.ck;
         const int slot = cil / g.eps, e = cil - slot * g.eps;
         const int row = tp * g.cgw + col;
-        const int64_t off = (((int64_t)cg * g.nchunks + chunk) * 9 * g.cgw + row) * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
+        const int64_t off = (((int64_t)cg * g.nchunks + chunk) * kk * g.cgw + row) * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
         char* dst = (char*)s.dst + off;
         if (s.compute == TR_BF16) ((unsigned short*)dst)[e] = tr::f32_to_bf16(val);
         else ((float*)dst)[e] = val;

@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int TW = 32, TH = 8, HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int TW = 32, TH = 8;
 constexpr int NTHREADS = 192;
 constexpr int CKW = 32;   // input channels per workgroup
 
@@ -36,8 +36,12 @@ struct WgArgs {
     int ntx, nty, ntiles, nslots, nchunks, ncg;
 };
 
-template <int CT, int NT>
+template <int CT, int NT, int KS>
 __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void wgrad_kernel(WgArgs a) {
+    // KS = 3: wave = ky, three kx accumulators.  KS = 1 (nn.Linear over tokens): one tap; the three waves take interleaved
+    // tile rows and emit their own partial blocks (the reduction kernel sums 3x as many).
+    constexpr int PAD = KS / 2;
+    constexpr int HALO_W = TW + KS - 1, HALO_H = TH + KS - 1;
     constexpr int ES = CT == TR_BF16 ? 2 : 4;
     constexpr int EPS = 16 / ES;
     constexpr int CG = NT * 32;
@@ -57,16 +61,18 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
     const int lr = l & 31, lh = l >> 5;
     const int slot = blockIdx.x, chunk = blockIdx.y, cg = blockIdx.z;
 
-    f32x16 acc[3][NT];
+    f32x16 acc[KS][NT];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < KS; ++k)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[k][t][i] = 0.f;
 
     // bias gradient rides along in the (chunk 0, ky 0) wave: column sums of the gy fragments it already holds
-    const bool do_bias = (a.db_partials != nullptr) & (chunk == 0) & (ky == 0);
+    const bool do_bias = (a.db_partials != nullptr) & (chunk == 0) & ((KS == 1) | (ky == 0));
+    const int kyo = KS == 3 ? ky : 0;          // row offset of this wave's tap
+    const int r_first = KS == 3 ? 0 : ky, r_step = KS == 3 ? 1 : 3;
     float bsum[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) bsum[t] = 0.f;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
             const int it = tb + j * NTHREADS;                                                                            \
             const int pp = it / XSLOTS, s_ = it - pp * XSLOTS;                                                           \
             const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
-            int oy = y0_ + py - 1, ox = x0_ + px - 1;                                                                    \
+            int oy = y0_ + py - PAD, ox = x0_ + px - PAD;                                                                    \
             bool ok = (it < X_ITEMS) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);                                  \
             if (a.replicate) {                                                                                          \
                 oy = min(max(oy, 0), a.h - 1);                                                                           \
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
             const int li = l & 15, q = li >> 2, p = li & 3;
             const int i0 = ((l >> 4) & 1) * 16;
 #pragma unroll 2
-            for (int r = 0; r < TH; ++r) {
+            for (int r = r_first; r < TH; r += r_step) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     bf16x8 af[NT];
@@ -176,8 +182,8 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
                         }
                     }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int hp = (r + ky) * HALO_W + kb * 16 + kx + 8 * lh + q;
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const int hp = (r + kyo) * HALO_W + kb * 16 + kx + 8 * lh + q;
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (__attribute__((address_space(3))) s16x4*)(xl + hp * XPIX_BYTES + (i0 + 4 * p) * 2));
                         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
                 }
             }
         } else {
-            for (int r = 0; r < TH; ++r) {
+            for (int r = r_first; r < TH; r += r_step) {
 #pragma unroll 4
                 for (int kp = 0; kp < 16; ++kp) {
                     float af[NT];
@@ -201,8 +207,8 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
                         if (do_bias) bsum[t2] += af[t2];
                     }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float bf = *(const float*)(xl + ((r + ky) * HALO_W + kp * 2 + lh + kx) * XPIX_BYTES + lr * 4);
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const float bf = *(const float*)(xl + ((r + kyo) * HALO_W + kp * 2 + lh + kx) * XPIX_BYTES + lr * 4);
 #pragma unroll
                         for (int t2 = 0; t2 < NT; ++t2)
                             acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t2], bf, acc[kx][t2], 0, 0, 0);
@@ -216,35 +222,37 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2) {
             const float v = bsum[t2] + __shfl_xor(bsum[t2], 32, 64);   // the two lane halves hold disjoint pixels of one channel
-            if (lh == 0) a.db_partials[((int64_t)slot * a.ncg + cg) * CG + t2 * 32 + lr] = v;
+            const int64_t sl = KS == 3 ? slot : (int64_t)slot * 3 + ky;
+            if (lh == 0) a.db_partials[(sl * a.ncg + cg) * CG + t2 * 32 + lr] = v;
         }
     }
 #undef TR_WG_ISSUE
     // partial block: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
-    float* dst = a.partials + (((int64_t)slot * a.nchunks + chunk) * a.ncg + cg) * (CG * 9 * CKW);
+    const int64_t slot_eff = KS == 3 ? slot : (int64_t)slot * 3 + ky;
+    float* dst = a.partials + ((slot_eff * a.nchunks + chunk) * a.ncg + cg) * (CG * KS * KS * CKW);
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = t2 * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-                dst[(co * 9 + ky * 3 + kx) * CKW + lr] = acc[kx][t2][reg];
+                dst[(co * (KS * KS) + kyo * KS + kx) * CKW + lr] = acc[kx][t2][reg];
             }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
-                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate) {
+                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps) {
     // one thread per (co, tap, ci) with ci fastest so partial reads are coalesced
-    const int64_t total = (int64_t)cout * 9 * cin;
+    const int64_t total = (int64_t)cout * taps * cin;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(i % cin);
-        const int tap = (int)((i / cin) % 9);
-        const int co = (int)(i / ((int64_t)cin * 9));
+        const int tap = (int)((i / cin) % taps);
+        const int co = (int)(i / ((int64_t)cin * taps));
         const int chunk = ci / CKW, cil = ci - chunk * CKW;
         const int cg = co / cgw, col = co - cg * cgw;
-        const int64_t blk = (int64_t)cgw * 9 * CKW;
-        const float* p = partials + ((int64_t)chunk * ncg + cg) * blk + ((int64_t)col * 9 + tap) * CKW + cil;
+        const int64_t blk = (int64_t)cgw * taps * CKW;
+        const float* p = partials + ((int64_t)chunk * ncg + cg) * blk + ((int64_t)col * taps + tap) * CKW + cil;
         const int64_t stride = (int64_t)nchunks * ncg * blk;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // fixed association: reproducible
         int k = 0;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         for (; k < nslots; ++k) s0 += p[k * stride];
         const float s = (s0 + s1) + (s2 + s3);
-        float* o = dw + ((int64_t)co * cin + ci) * 9 + tap;
+        float* o = dw + ((int64_t)co * cin + ci) * taps + tap;
         *o = accumulate ? *o + s : s;
     }
 }
@@ -281,7 +289,7 @@ struct Plan {
     size_t dw_floats, db_floats;
 };
 
-Plan make_plan(int n, int h, int w, int cin, int cout) {
+Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3) {
     Plan p;
     p.ntx = (w + TW - 1) / TW;
     p.nty = (h + TH - 1) / TH;
@@ -292,21 +300,22 @@ Plan make_plan(int n, int h, int w, int cin, int cout) {
     int target = 768 / (p.nchunks * p.ncg);      // ~3 workgroups of 3 waves per CU
     if (target < 1) target = 1;
     p.nslots = p.ntiles < target ? p.ntiles : target;
-    p.dw_floats = (size_t)p.nslots * p.nchunks * p.ncg * p.cgw * 9 * CKW;
-    p.db_floats = (size_t)p.nslots * p.ncg * p.cgw;
+    const int mult = ks == 1 ? 3 : 1;
+    p.dw_floats = (size_t)p.nslots * mult * p.nchunks * p.ncg * p.cgw * ks * ks * CKW;
+    p.db_floats = (size_t)p.nslots * mult * p.ncg * p.cgw;
     return p;
 }
 
-template <int CT, int NT>
+template <int CT, int NT, int KS>
 int launch_wgrad(hipStream_t st, const WgArgs& a) {
     constexpr int ES = CT == TR_BF16 ? 2 : 4;
-    constexpr size_t lds = (size_t)HALO_H * HALO_W * CKW * ES + (size_t)TH * TW * NT * 32 * ES;
+    constexpr size_t lds = (size_t)(TH + KS - 1) * (TW + KS - 1) * CKW * ES + (size_t)TH * TW * NT * 32 * ES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad_kernel<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)wgrad_kernel<CT, NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<CT, NT>), dim3(a.nslots, a.nchunks, a.ncg), dim3(NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((wgrad_kernel<CT, NT, KS>), dim3(a.nslots, a.nchunks, a.ncg), dim3(NTHREADS), lds, st, a);
     return tr::launch_status("tr_wgrad3x3");
 }
 
@@ -315,6 +324,11 @@ int launch_wgrad(hipStream_t st, const WgArgs& a) {
 extern "C" size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     const Plan p = make_plan(n, h, w, cin, cout);
+    return (p.dw_floats + p.db_floats) * sizeof(float);
+}
+extern "C" size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
+    const Plan p = make_plan(n, h, w, cin, cout, ksize);
     return (p.dw_floats + p.db_floats) * sizeof(float);
 }
 
@@ -331,7 +345,8 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     TR_REQUIRE(tr::view_vec16B_ok(d->in) && tr::view_vec16B_ok(d->gy), TR_EALIGN, "tr_wgrad3x3: views are not 16-byte sliceable");
     TR_REQUIRE(d->in.coff + d->in.c <= d->in.cstride && d->gy.coff + d->gy.c <= d->gy.cstride, TR_EINVAL, "tr_wgrad3x3: view exceeds its buffer");
     TR_REQUIRE(d->in_mode == TR_IN_DIRECT || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL, "tr_wgrad3x3: nearest-2x input needs even dims");
-    const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout);
+    TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_wgrad3x3: ksize must be 3 or 1");
+    const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout, d->ksize);
     TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
                "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
 
@@ -347,20 +362,27 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     a.ntx = p.ntx; a.nty = p.nty; a.ntiles = p.ntiles; a.nslots = p.nslots; a.nchunks = p.nchunks; a.ncg = p.ncg;
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2>(st, a) : launch_wgrad<TR_BF16, 1>(st, a);
-    else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2>(st, a) : launch_wgrad<TR_F32, 1>(st, a);
+    if (d->ksize == 1) {
+        if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2, 1>(st, a) : launch_wgrad<TR_BF16, 1, 1>(st, a);
+        else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2, 1>(st, a) : launch_wgrad<TR_F32, 1, 1>(st, a);
+    } else {
+        if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2, 3>(st, a) : launch_wgrad<TR_BF16, 1, 3>(st, a);
+        else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2, 3>(st, a) : launch_wgrad<TR_F32, 1, 3>(st, a);
+    }
     if (rc) return rc;
     {
-        const int64_t total = (int64_t)d->cout * 9 * d->cin;
+        const int taps = d->ksize * d->ksize;
+        const int mult = d->ksize == 1 ? 3 : 1;
+        const int64_t total = (int64_t)d->cout * taps * d->cin;
         int64_t b = (total + 255) / 256;
         if (b > 2048) b = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots, p.nchunks,
-                           p.ncg, p.cgw, d->accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult, p.nchunks,
+                           p.ncg, p.cgw, d->accumulate, taps);
         rc = tr::launch_status("tr_wgrad3x3(reduce)");
         if (rc) return rc;
     }
     if (d->db) {
-        hipLaunchKernelGGL(db_finish_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, st, d->partials + p.dw_floats, p.nslots, p.ncg, p.cgw,
+        hipLaunchKernelGGL(db_finish_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, st, d->partials + p.dw_floats, p.nslots * (d->ksize == 1 ? 3 : 1), p.ncg, p.cgw,
                            d->cout, d->db, d->accumulate);
         rc = tr::launch_status("tr_wgrad3x3(bias finish)");
     }

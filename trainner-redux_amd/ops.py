@@ -52,13 +52,13 @@ def view(t: torch.Tensor | None, coff: int = 0, c: int | None = None) -> L.View:
 NULL_VIEW = L.View(None, 0, 0, 0, 0)
 
 
-def packed_bytes(cin: int, cout: int, compute: int) -> int:
-    return int(L.lib().tr_conv3x3_packed_bytes(cin, cout, compute))
+def packed_bytes(cin: int, cout: int, compute: int, ksize: int = 3) -> int:
+    return int(L.lib().tr_conv_packed_bytes(cin, cout, compute, ksize))
 
 
 def conv3x3(*, n, h, w, cin, cout, compute, inp: L.View, out: L.View, wpacked: torch.Tensor, bias: torch.Tensor | None = None,
             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, act=L.ACT_NONE, slope=0.2, res1: L.View = NULL_VIEW, scale1=1.0,
-            res2: L.View = NULL_VIEW, scale2=1.0, res1_scale=1.0, res2_scale=1.0, mask: L.View = NULL_VIEW, mask_slope=0.2, out2: L.View = NULL_VIEW, out2_scale=1.0):
+            res2: L.View = NULL_VIEW, scale2=1.0, res1_scale=1.0, res2_scale=1.0, ksize=3, mask_mode=0, sample_scale: torch.Tensor | None = None, mask: L.View = NULL_VIEW, mask_slope=0.2, out2: L.View = NULL_VIEW, out2_scale=1.0):
     d = L.Conv3x3Desc()
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.compute, d.in_mode, d.pad_mode, d.act = compute, in_mode, pad_mode, act
@@ -67,6 +67,8 @@ def conv3x3(*, n, h, w, cin, cout, compute, inp: L.View, out: L.View, wpacked: t
     d.inp, d.out, d.out2, d.res1, d.res2, d.mask = inp, out, out2, res1, res2, mask
     d.wpacked = wpacked.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
+    d.ksize, d.mask_mode = ksize, mask_mode
+    d.sample_scale = sample_scale.data_ptr() if sample_scale is not None else None
     L.check(L.lib().tr_conv3x3(stream_ptr(), C.byref(d)), "tr_conv3x3")
 
 
@@ -82,14 +84,19 @@ class PackPlan:
 
     def add(self, src: torch.Tensor, dst: torch.Tensor, dst_cin: int, dst_cout: int, compute: int, *, o_off=0, o_cnt=None, i_off=0,
             i_cnt=None, dst_o_off=0, dst_i_off=0, transpose=False):
-        assert src.dtype == torch.float32 and src.is_contiguous() and src.dim() == 4 and src.shape[2:] == (3, 3)
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        if src.dim() == 2:
+            ks = 1                                   # nn.Linear weight (out_features, in_features)
+        else:
+            assert src.dim() == 4 and src.shape[2] == src.shape[3] and src.shape[2] in (1, 3)
+            ks = src.shape[2]
         so, si = src.shape[0], src.shape[1]
         o_cnt = so - o_off if o_cnt is None else o_cnt
         i_cnt = si - i_off if i_cnt is None else i_cnt
         s = L.PackSeg(src.data_ptr(), dst.data_ptr(), so, si, o_off, o_cnt, i_off, i_cnt, dst_cin, dst_cout, dst_o_off, dst_i_off,
-                      1 if transpose else 0, compute, self.total)
+                      1 if transpose else 0, compute, ks, 0, self.total)
         self.segs.append(s)
-        self.total += o_cnt * i_cnt * 9
+        self.total += o_cnt * i_cnt * ks * ks
         self._keep.append((src, dst))
         self._dev = None
 
@@ -108,17 +115,18 @@ class PackPlan:
         L.check(L.lib().tr_pack_conv3x3(stream_ptr(), self._dev.data_ptr(), len(self.segs), self.total), "tr_pack_conv3x3")
 
 
-def wgrad_workspace_bytes(n, h, w, cin, cout) -> int:
-    return int(L.lib().tr_wgrad3x3_workspace_bytes(n, h, w, cin, cout))
+def wgrad_workspace_bytes(n, h, w, cin, cout, ksize: int = 3) -> int:
+    return int(L.lib().tr_wgrad_workspace_bytes(n, h, w, cin, cout, ksize))
 
 
 def wgrad3x3(*, n, h, w, cin, cout, compute, inp: L.View, gy: L.View, dw: torch.Tensor, db: torch.Tensor | None, workspace: torch.Tensor,
-             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, accumulate=False):
+             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, accumulate=False, ksize=3):
     d = L.Wgrad3x3Desc()
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.compute, d.in_mode, d.pad_mode, d.accumulate = compute, in_mode, pad_mode, 1 if accumulate else 0
     d.inp, d.gy = inp, gy
-    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * 9
+    d.ksize = ksize
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * ksize * ksize
     d.dw = dw.data_ptr()
     d.db = db.data_ptr() if db is not None else None
     d.partials = workspace.data_ptr()
