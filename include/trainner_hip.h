@@ -174,6 +174,9 @@ int tr_nhwc_to_nchw(void* stream, tr_view src, float* dst, int n, int c_dst, int
 /* gradient of tr_nchw_to_nhwc wrt src: dst_nchw[c] = g[c] / std[c] */
 int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w,
                            const float* inv_std3, int accumulate);
+/* dst[c] = src[c] * scale[c] + offset[c]  (SwinIR's `x / img_range + mean` on the way out; host pointers, 3 floats each) */
+int tr_nhwc_to_nchw_affine(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w, const float* scale3_host,
+                           const float* offset3_host);
 /* out = (out.dtype)((a*sa + b*sb) * (mask > 0 ? 1 : mask_slope)) for NHWC views of equal shape (b and mask optional) --
  * residual / skip adds of activations and gradient streams, dtype conversion, LeakyReLU derivative of a skip branch */
 int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope);
@@ -251,6 +254,40 @@ typedef struct tr_gan_loss_desc {
     float*  partials;         /* >= 1024 floats                              */
 } tr_gan_loss_desc;
 int tr_gan_loss(void* stream, const tr_gan_loss_desc* d);
+
+/* ---- SwinIR token path (in-tree twin of spandrel's SwinIR: traiNNer/archs/drct_arch.py) ---------------------------------
+ * Tokens are the pixels of an NHWC tensor ([ntok][channels]); nn.Linear layers are tr_conv3x3 with ksize 1.
+ * LayerNorm over the c logical channels of x (:464,476,658-662), eps as given; channels [c, y.c) of y are zeroed (K padding of
+ * the following GEMM); mean / rstd (ntok floats each, optional) are kept for the backward. */
+int tr_layernorm(void* stream, tr_view x, tr_view y, int64_t ntok, int c, const float* gamma, const float* beta, float eps,
+                 float* mean_out, float* rstd_out);
+/* dx = (res ? res : 0) + dLN/dx ; dgamma / dbeta (+)= ...  (fixed-order reduction; workspace from the _bytes call) */
+size_t tr_layernorm_bwd_workspace_bytes(int c);
+int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok, int c, const float* gamma, const float* mean, const float* rstd,
+                     tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes);
+
+/* (Shifted-)window multi-head self-attention core (:175-223, roll / partition / reverse :78-109,:532-568, mask :492-521):
+ * per 8x8 window and head  softmax(q*scale @ k^T + table[rel_index] + shift_mask) @ v, windows taken from the image rolled by
+ * -shift; qkv holds [q | k | v], each c = nh*hd channels; out receives the attention output at the ORIGINAL token positions.
+ * Backward recomputes the probabilities; dqkv receives d/dq, d/dk, d/dv; dtable (+)= d/d(relative_position_bias_table). */
+typedef struct tr_window_attn_desc {
+    tr_view qkv, out;         /* forward operands (out unused in backward)                           */
+    tr_view dout, dqkv;       /* backward operands                                                   */
+    const float* table;       /* (2*window-1)^2 x nh fp32                                            */
+    float*  dtable;           /* backward: gradient of the table or NULL                             */
+    float*  dbias_ws;         /* backward: tr_window_attention_bwd_workspace_bytes() bytes, needed with dtable */
+    int32_t b, h, w;          /* batch, token-grid height / width (multiples of window)              */
+    int32_t c, nh;            /* embedding width and head count (c / nh <= 32)                        */
+    int32_t window, shift;    /* 8 ; 0 or window/2                                                   */
+    float   scale;            /* head_dim ** -0.5                                                    */
+    int32_t accumulate_dtable;
+} tr_window_attn_desc;
+int    tr_window_attention(void* stream, const tr_window_attn_desc* d);
+size_t tr_window_attention_bwd_workspace_bytes(int b, int h, int w, int nh);
+int    tr_window_attention_bwd(void* stream, const tr_window_attn_desc* d);
+/* nn.PixelShuffle(r) on NHWC views (:714-717): out[n, y*r+dy, x*r+dx, ch] = in[n, y, x, ch*r*r + dy*r + dx]; inverse != 0 is
+ * pixel_unshuffle (its adjoint).  n, h, w are the LOW-resolution dims, c the high-resolution channel count. */
+int tr_pixel_shuffle(void* stream, tr_view in, tr_view out, int n, int h, int w, int c, int r, int inverse);
 
 /* ---- optimizer sweep --------------------------------------------------------------------------
  * torch.optim.AdamW (optimizers/__init__.py:30-47, templates: lr 2e-4, betas (0.9, 0.99), wd 0)

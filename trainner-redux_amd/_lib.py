@@ -78,6 +78,15 @@ class GanLossDesc(C.Structure):
     ]
 
 
+class WindowAttnDesc(C.Structure):
+    _fields_ = [
+        ("qkv", View), ("out", View), ("dout", View), ("dqkv", View),
+        ("table", C.c_void_p), ("dtable", C.c_void_p), ("dbias_ws", C.c_void_p),
+        ("b", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("nh", C.c_int32), ("window", C.c_int32), ("shift", C.c_int32),
+        ("scale", C.c_float), ("accumulate_dtable", C.c_int32),
+    ]
+
+
 class AdamWDesc(C.Structure):
     _fields_ = [
         ("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
@@ -105,6 +114,15 @@ SYMBOLS = {
     "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_nhwc_to_nchw_scaled": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "tr_nhwc_to_nchw_affine": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tr_layernorm": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "tr_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "tr_layernorm_bwd": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_size_t]),
+    "tr_window_attention": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),
+    "tr_window_attention_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_window_attention_bwd": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),
+    "tr_pixel_shuffle": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64, View, C.c_float]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
     "tr_depth_to_space2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtrainner_hip.so")
-SOURCES = ["common.hip", "conv3x3.hip", "pack.hip", "wgrad3x3.hip", "eltwise.hip", "loss.hip", "optim.hip", "stem.hip", "disc.hip"]
+SOURCES = ["common.hip", "conv3x3.hip", "pack.hip", "wgrad3x3.hip", "eltwise.hip", "loss.hip", "optim.hip", "stem.hip", "disc.hip", "token.hip"]
 
 
 def _stale() -> bool:

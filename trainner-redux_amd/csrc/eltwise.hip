@@ -28,13 +28,13 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tr_view src, float* __restrict__ dst, int c_dst, int64_t hw, int64_t npix,
-                                                            float3 scale, int use_scale, int accumulate) {
+                                                            float3 scale, int use_scale, int accumulate, float3 offset = make_float3(0.f, 0.f, 0.f)) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (int64_t)gridDim.x * blockDim.x) {
         const int64_t nb = p / hw, s = p - nb * hw;
         float* dp = dst + nb * c_dst * hw + s;
         for (int c = 0; c < c_dst; ++c) {
             float v = tr::view_load(src, p, c);
-            if (use_scale) v *= (c == 0 ? scale.x : (c == 1 ? scale.y : scale.z));
+            if (use_scale) v = v * (c == 0 ? scale.x : (c == 1 ? scale.y : scale.z)) + (c == 0 ? offset.x : (c == 1 ? offset.y : offset.z));
             if (accumulate) v += dp[(int64_t)c * hw];
             dp[(int64_t)c * hw] = v;
         }
@@ -181,6 +181,15 @@ extern "C" int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, c_dst, (int64_t)h * w,
                        npix, make_float3(inv_std3[0], inv_std3[1], inv_std3[2]), 1, accumulate);
     return tr::launch_status("tr_nhwc_to_nchw_scaled");
+}
+
+extern "C" int tr_nhwc_to_nchw_affine(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w, const float* scale3,
+                                      const float* offset3) {
+    TR_REQUIRE(src.ptr && dst && n > 0 && c_dst == 3 && src.c >= 3 && scale3 && offset3, TR_EINVAL, "tr_nhwc_to_nchw_affine: bad arguments");
+    const int64_t npix = (int64_t)n * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)stream, src, dst, c_dst, (int64_t)h * w, npix,
+                       make_float3(scale3[0], scale3[1], scale3[2]), 1, 0, make_float3(offset3[0], offset3[1], offset3[2]));
+    return tr::launch_status("tr_nhwc_to_nchw_affine");
 }
 
 extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope) {

@@ -1,0 +1,412 @@
+// Token-path kernels of the SwinIR block: LayerNorm, window attention (W-MSA / SW-MSA), PixelShuffle.
+//
+// Contract: include/trainner_hip.h.  Reference arithmetic replaced (in-tree twin of spandrel's SwinIR):
+//   nn.LayerNorm(dim)                          traiNNer/archs/drct_arch.py:464,476,658-662
+//   WindowAttention.forward                    traiNNer/archs/drct_arch.py:175-223  (q*scale, q@k^T, + relative-position bias
+//                                              gathered from the (2w-1)^2 x heads table, + shift mask (0/-100, :492-521), softmax, @v)
+//   torch.roll +-shift, window_partition/reverse  :78-109, :532-568  -> pure index arithmetic here (no copies)
+//   nn.PixelShuffle                            :714-717
+// Mapping to gfx950: one wave per (window, head); lane = query token.  A 64-token window row of scores lives in the lane's
+// registers, so the softmax max/sum are lane-local (no cross-lane traffic at all); K and V sit in LDS and are read as broadcasts.
+// The contractions here are 6 % of SwinIR's FLOPs and run on the VALU in fp32; the Linear layers
+// (71 %) and convs (22 %) are on MFMA (conv3x3.hip, ksize 1 / 3).
+#include "common.h"
+
+namespace {
+
+constexpr int WS = 8, WT = 64, HDMAX = 32;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- LayerNorm: one wave per token, lane owns channels lane, lane+64, ... ------------------------------------------------
+constexpr int LN_MAXK = 12;   // C <= 768
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(tr_view x, tr_view y, int64_t ntok, int c, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out) {
+    const int l = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t t = wave; t < ntok; t += nwaves) {
+        float v[LN_MAXK];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int ch = l + 64 * k;
+            v[k] = ch < c ? tr::view_load(x, t, ch) : 0.f;
+            s += v[k];
+        }
+        const float mean = wave_sum(s) / (float)c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int ch = l + 64 * k;
+            const float d = ch < c ? v[k] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int ch = l + 64 * k;
+            if (ch < y.c) tr::view_store(y, t, ch, ch < c ? (v[k] - mean) * rstd * gamma[ch] + beta[ch] : 0.f);
+        }
+        if (l == 0 && mean_out) { mean_out[t] = mean; rstd_out[t] = rstd; }
+    }
+}
+
+// dx = rstd * (a - mean_c(a) - xhat * mean_c(a * xhat)), a = g * gamma ;  out = (res ? res : 0) + dx
+// partial dgamma / dbeta per block -> partials[block][2][c]
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(tr_view g, tr_view x, int64_t ntok, int c, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, tr_view res,
+                                                             tr_view dx, float* __restrict__ partials) {
+    __shared__ float sh[4][2][LN_MAXK * 64];
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
+    float dg[LN_MAXK], db[LN_MAXK];
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) dg[k] = db[k] = 0.f;
+    for (int64_t t = wave; t < ntok; t += nwaves) {
+        const float mu = mean[t], rs = rstd[t];
+        float a[LN_MAXK], xh[LN_MAXK];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int ch = l + 64 * k;
+            if (ch < c) {
+                const float gv = tr::view_load(g, t, ch);
+                xh[k] = (tr::view_load(x, t, ch) - mu) * rs;
+                a[k] = gv * gamma[ch];
+                dg[k] += gv * xh[k];
+                db[k] += gv;
+            } else { a[k] = 0.f; xh[k] = 0.f; }
+            s1 += a[k];
+            s2 += a[k] * xh[k];
+        }
+        const float m1 = wave_sum(s1) / (float)c, m2 = wave_sum(s2) / (float)c;
+#pragma unroll
+        for (int k = 0; k < LN_MAXK; ++k) {
+            const int ch = l + 64 * k;
+            if (ch < c) {
+                float o = rs * (a[k] - m1 - xh[k] * m2);
+                if (res.ptr) o += tr::view_load(res, t, ch);
+                tr::view_store(dx, t, ch, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXK; ++k) { sh[wv][0][l + 64 * k] = dg[k]; sh[wv][1][l + 64 * k] = db[k]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
+        const int which = i / c, ch = i - which * c;
+        partials[(int64_t)blockIdx.x * 2 * c + i] = (sh[0][which][ch] + sh[1][which][ch]) + (sh[2][which][ch] + sh[3][which][ch]);
+    }
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* __restrict__ partials, int nblocks, int c, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * c) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * 2 * c + i];
+    float* o = i < c ? dgamma + i : dbeta + (i - c);
+    *o = accumulate ? *o + s : s;
+}
+
+// ---- window attention ----------------------------------------------------------------------------------------------------
+struct AttnArgs {
+    tr_view qkv, out;          // forward: qkv (fp32 or bf16, [q | k | v] x heads x hd), out = attention output (C channels)
+    tr_view dout, dqkv;        // backward
+    const float* table;        // (2*WS-1)^2 x nh
+    float* dbias_ws;           // backward: [b*nW + win][nh][64][64]
+    int b, h, w, nh, hd, c, shift;
+    float scale;
+};
+
+__device__ __forceinline__ int region(int s, int n, int shift) { return s < n - WS ? 0 : (s < n - shift ? 1 : 2); }
+
+// score row of query i against the 64 keys in LDS, + relative-position bias + shift mask; returns row max
+template <bool DUMMY>
+__device__ __forceinline__ void score_row(const AttnArgs& a, const float* q, const float* kl, int i, int head, int wy, int wx, float (&s)[WT]) {
+    const int iy = i >> 3, ix = i & 7;
+    const int ri = a.shift ? region(wy * WS + iy, a.h, a.shift) * 3 + region(wx * WS + ix, a.w, a.shift) : 0;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < HDMAX; ++d) acc += q[d] * kl[j * HDMAX + d];   // head_dim is zero-padded to 32 in registers and LDS
+        const int jy = j >> 3, jx = j & 7;
+        acc += a.table[((iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1)) * a.nh + head];
+        if (a.shift) {
+            const int rj = region(wy * WS + jy, a.h, a.shift) * 3 + region(wx * WS + jx, a.w, a.shift);
+            if (rj != ri) acc += -100.f;
+        }
+        s[j] = acc;
+    }
+}
+
+__device__ __forceinline__ void softmax_row(float (&s)[WT]) {
+    float m = s[0];
+#pragma unroll
+    for (int j = 1; j < WT; ++j) m = fmaxf(m, s[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) { s[j] = expf(s[j] - m); sum += s[j]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) s[j] *= inv;
+}
+
+__device__ __forceinline__ int64_t token_of(const AttnArgs& a, int bb, int wy, int wx, int i) {
+    // shifted-window coordinates -> original image coordinates (torch.roll by -shift before partition, +shift after reverse)
+    const int y = (wy * WS + (i >> 3) + a.shift) % a.h, x = (wx * WS + (i & 7) + a.shift) % a.w;
+    return ((int64_t)bb * a.h + y) * a.w + x;
+}
+
+__global__ __launch_bounds__(64) void window_attn_fwd_kernel(AttnArgs a) {
+    __shared__ float kl[WT * HDMAX], vl[WT * HDMAX];
+    const int i = threadIdx.x;
+    int blk = blockIdx.x;
+    const int head = blk % a.nh; blk /= a.nh;
+    const int nwx = a.w / WS, nwy = a.h / WS;
+    const int wx = blk % nwx; blk /= nwx;
+    const int wy = blk % nwy;
+    const int bb = blk / nwy;
+    const int64_t t = token_of(a, bb, wy, wx, i);
+    float q[HDMAX];
+#pragma unroll
+    for (int d = 0; d < HDMAX; ++d) {
+        const bool ok = d < a.hd;
+        q[d] = ok ? tr::view_load(a.qkv, t, head * a.hd + d) * a.scale : 0.f;
+        kl[i * HDMAX + d] = ok ? tr::view_load(a.qkv, t, a.c + head * a.hd + d) : 0.f;
+        vl[i * HDMAX + d] = ok ? tr::view_load(a.qkv, t, 2 * a.c + head * a.hd + d) : 0.f;
+    }
+    __syncthreads();
+    float s[WT];
+    score_row<true>(a, q, kl, i, head, wy, wx, s);
+    softmax_row(s);
+#pragma unroll
+    for (int d = 0; d < HDMAX; ++d) {
+        float o = 0.f;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) o += s[j] * vl[j * HDMAX + d];
+        if (d < a.hd) tr::view_store(a.out, t, head * a.hd + d, o);
+    }
+}
+
+__global__ __launch_bounds__(64) void window_attn_bwd_kernel(AttnArgs a) {
+    // q (scaled), k, v and dO of the window live in LDS with rows padded to 33 floats: a lane reading ITS row is conflict free,
+    // all lanes reading the SAME row is a broadcast.  Only the 64-wide score / probability rows are register arrays.
+    constexpr int HP = HDMAX + 1;
+    extern __shared__ float sm[];
+    float* kl = sm;
+    float* vl = kl + WT * HP;
+    float* ql = vl + WT * HP;
+    float* gl = ql + WT * HP;
+    float* dsl = gl + WT * HP;            // dS  [64][65]
+    float* pl = dsl + WT * (WT + 1);      // P   [64][65]
+    const int i = threadIdx.x;
+    int blk = blockIdx.x;
+    const int head = blk % a.nh; blk /= a.nh;
+    const int nwx = a.w / WS, nwy = a.h / WS;
+    const int wx = blk % nwx; blk /= nwx;
+    const int wy = blk % nwy;
+    const int bb = blk / nwy;
+    const int64_t t = token_of(a, bb, wy, wx, i);
+    const int hd = a.hd;
+    for (int d = 0; d < hd; ++d) {
+        ql[i * HP + d] = tr::view_load(a.qkv, t, head * hd + d) * a.scale;
+        gl[i * HP + d] = tr::view_load(a.dout, t, head * hd + d);
+        kl[i * HP + d] = tr::view_load(a.qkv, t, a.c + head * hd + d);
+        vl[i * HP + d] = tr::view_load(a.qkv, t, 2 * a.c + head * hd + d);
+    }
+    __syncthreads();
+    const int iy = i >> 3, ix = i & 7;
+    const int ri = a.shift ? region(wy * WS + iy, a.h, a.shift) * 3 + region(wx * WS + ix, a.w, a.shift) : 0;
+    float s[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc += ql[i * HP + d] * kl[j * HP + d];
+        const int jy = j >> 3, jx = j & 7;
+        acc += a.table[((iy - jy + WS - 1) * (2 * WS - 1) + (ix - jx + WS - 1)) * a.nh + head];
+        if (a.shift) {
+            const int rj = region(wy * WS + jy, a.h, a.shift) * 3 + region(wx * WS + jx, a.w, a.shift);
+            if (rj != ri) acc += -100.f;
+        }
+        s[j] = acc;
+    }
+    softmax_row(s);                                      // s = P row
+    float delta = 0.f;
+    float dp[WT];
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc += gl[i * HP + d] * vl[j * HP + d];
+        dp[j] = acc;
+        delta += acc * s[j];
+    }
+    float* dbw = a.dbias_ws ? a.dbias_ws + ((((int64_t)bb * nwy + wy) * nwx + wx) * a.nh + head) * (WT * WT) + (int64_t)i * WT : nullptr;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+        const float ds = s[j] * (dp[j] - delta);
+        dsl[i * (WT + 1) + j] = ds;
+        pl[i * (WT + 1) + j] = s[j];
+        if (dbw) dbw[j] = ds;
+        dp[j] = ds;
+    }
+    // dQ_i = scale * sum_j dS[i][j] K_j
+    for (int d = 0; d < hd; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) acc += dp[j] * kl[j * HP + d];
+        tr::view_store(a.dqkv, t, head * hd + d, acc * a.scale);
+    }
+    __syncthreads();
+    // lane now acts as key/value token j = i:  dK_j = sum_i dS[i][j] * qs_i ;  dV_j = sum_i P[i][j] * dO_i
+    for (int d = 0; d < hd; ++d) {
+        float dk = 0.f, dv = 0.f;
+        for (int r = 0; r < WT; ++r) {
+            dk += dsl[r * (WT + 1) + i] * ql[r * HP + d];
+            dv += pl[r * (WT + 1) + i] * gl[r * HP + d];
+        }
+        tr::view_store(a.dqkv, t, a.c + head * hd + d, dk);
+        tr::view_store(a.dqkv, t, 2 * a.c + head * hd + d, dv);
+    }
+}
+
+// dbias_full[h][i][j] = sum over (batch, window) ; then table_grad[idx][h] += sum over (i,j) with rel-index idx
+__global__ __launch_bounds__(256) void dbias_sum_kernel(const float* __restrict__ ws, int nbw, int nh, float* __restrict__ full) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh * WT * WT) return;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 2 <= nbw; k += 2) { s0 += ws[(int64_t)k * nh * WT * WT + i]; s1 += ws[(int64_t)(k + 1) * nh * WT * WT + i]; }
+    if (k < nbw) s0 += ws[(int64_t)k * nh * WT * WT + i];
+    full[i] = s0 + s1;
+}
+__global__ __launch_bounds__(256) void dbias_table_kernel(const float* __restrict__ full, int nh, float* __restrict__ dtable, int accumulate) {
+    const int tdx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ntab = (2 * WS - 1) * (2 * WS - 1);
+    if (tdx >= ntab * nh) return;
+    const int idx = tdx / nh, head = tdx - idx * nh;
+    const int dy = idx / (2 * WS - 1) - (WS - 1), dx = idx % (2 * WS - 1) - (WS - 1);   // iy - jy, ix - jx
+    float s = 0.f;
+    for (int iy = 0; iy < WS; ++iy) {
+        const int jy = iy - dy;
+        if (jy < 0 || jy >= WS) continue;
+        for (int ix = 0; ix < WS; ++ix) {
+            const int jx = ix - dx;
+            if (jx < 0 || jx >= WS) continue;
+            s += full[(head * WT + (iy * WS + ix)) * WT + (jy * WS + jx)];
+        }
+    }
+    dtable[tdx] = accumulate ? dtable[tdx] + s : s;
+}
+
+// ---- PixelShuffle(r): out[n, y*r+dy, x*r+dx, c] = in[n, y, x, c*r*r + dy*r + dx] ; inverse = pixel_unshuffle ------------------
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(tr_view in, tr_view out, int n, int h, int w, int c, int r, int inverse) {
+    const int64_t total = (int64_t)n * h * w * c * r * r;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cc = (int)(t % (c * r * r)); t /= (c * r * r);
+        const int x = (int)(t % w); t /= w;
+        const int y = (int)(t % h);
+        const int nb = (int)(t / h);
+        const int ch = cc / (r * r), dy = (cc / r) % r, dx = cc % r;
+        const int64_t plow = ((int64_t)nb * h + y) * w + x;
+        const int64_t phigh = ((int64_t)nb * h * r + (y * r + dy)) * (w * r) + (x * r + dx);
+        if (inverse) tr::view_store(out, plow, cc, tr::view_load(in, phigh, ch));
+        else tr::view_store(out, phigh, ch, tr::view_load(in, plow, cc));
+    }
+}
+
+inline unsigned grid_for(int64_t work, int cap = 256 * 16) {
+    int64_t b = (work + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int tr_layernorm(void* stream, tr_view x, tr_view y, int64_t ntok, int c, const float* gamma, const float* beta, float eps,
+                            float* mean_out, float* rstd_out) {
+    TR_REQUIRE(x.ptr && y.ptr && gamma && beta && ntok > 0 && c > 0 && c <= LN_MAXK * 64 && x.c >= c && y.c >= c && y.c <= LN_MAXK * 64, TR_EINVAL,
+               "tr_layernorm: bad arguments (c <= %d)", LN_MAXK * 64);
+    TR_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr), TR_EINVAL, "tr_layernorm: mean/rstd outputs come together");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(ntok * 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, y, ntok, c, gamma, beta, eps, mean_out,
+                       rstd_out);
+    return tr::launch_status("tr_layernorm");
+}
+
+extern "C" int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok, int c, const float* gamma, const float* mean, const float* rstd,
+                                tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes) {
+    TR_REQUIRE(g.ptr && x.ptr && dx.ptr && gamma && mean && rstd && dgamma && dbeta && partials && ntok > 0 && c > 0 && c <= LN_MAXK * 64, TR_EINVAL,
+               "tr_layernorm_bwd: bad arguments");
+    int nb = (int)grid_for(ntok * 64, 512);
+    TR_REQUIRE(partials_bytes >= (size_t)nb * 2 * c * sizeof(float), TR_EINVAL, "tr_layernorm_bwd: workspace too small (need %zu bytes)",
+               (size_t)nb * 2 * c * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials);
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, partials, nb, c, dgamma, dbeta, accumulate);
+    return tr::launch_status("tr_layernorm_bwd");
+}
+extern "C" size_t tr_layernorm_bwd_workspace_bytes(int c) { return (size_t)512 * 2 * c * sizeof(float); }
+
+static int attn_check(const tr_window_attn_desc* d) {
+    TR_REQUIRE(d && d->qkv.ptr && d->table && d->b > 0 && d->h > 0 && d->w > 0 && d->nh > 0, TR_EINVAL, "tr_window_attention: bad arguments");
+    TR_REQUIRE(d->window == WS, TR_EUNSUPPORTED, "tr_window_attention: window size %d (only 8 is built)", d->window);
+    TR_REQUIRE(d->h % WS == 0 && d->w % WS == 0, TR_EINVAL, "tr_window_attention: H, W must be multiples of the window");
+    TR_REQUIRE(d->c % d->nh == 0 && d->c / d->nh <= HDMAX, TR_EUNSUPPORTED, "tr_window_attention: head_dim must be <= %d", HDMAX);
+    TR_REQUIRE(d->shift >= 0 && d->shift < WS && d->qkv.c >= 3 * d->c, TR_EINVAL, "tr_window_attention: bad shift / qkv width");
+    return 0;
+}
+static AttnArgs attn_args(const tr_window_attn_desc* d) {
+    AttnArgs a;
+    a.qkv = d->qkv; a.out = d->out; a.dout = d->dout; a.dqkv = d->dqkv; a.table = d->table; a.dbias_ws = d->dbias_ws;
+    a.b = d->b; a.h = d->h; a.w = d->w; a.nh = d->nh; a.c = d->c; a.hd = d->c / d->nh; a.shift = d->shift; a.scale = d->scale;
+    return a;
+}
+extern "C" int tr_window_attention(void* stream, const tr_window_attn_desc* d) {
+    int rc = attn_check(d);
+    if (rc) return rc;
+    TR_REQUIRE(d->out.ptr && d->out.c >= d->c, TR_EINVAL, "tr_window_attention: output view too narrow");
+    const int nblk = d->b * (d->h / WS) * (d->w / WS) * d->nh;
+    hipLaunchKernelGGL(window_attn_fwd_kernel, dim3(nblk), dim3(64), 0, (hipStream_t)stream, attn_args(d));
+    return tr::launch_status("tr_window_attention");
+}
+extern "C" size_t tr_window_attention_bwd_workspace_bytes(int b, int h, int w, int nh) {
+    return ((size_t)b * (h / WS) * (w / WS) * nh + (size_t)nh) * WT * WT * sizeof(float);
+}
+extern "C" int tr_window_attention_bwd(void* stream, const tr_window_attn_desc* d) {
+    int rc = attn_check(d);
+    if (rc) return rc;
+    TR_REQUIRE(d->dout.ptr && d->dqkv.ptr && d->dqkv.c >= 3 * d->c && d->dout.c >= d->c, TR_EINVAL, "tr_window_attention_bwd: gradient views too narrow");
+    TR_REQUIRE((d->dtable == nullptr) == (d->dbias_ws == nullptr), TR_EINVAL, "tr_window_attention_bwd: dtable and dbias_ws come together");
+    hipStream_t st = (hipStream_t)stream;
+    const int nbw = d->b * (d->h / WS) * (d->w / WS);
+    const size_t lds = (size_t)(4 * WT * (HDMAX + 1) + 2 * WT * (WT + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)window_attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nbw * d->nh), dim3(64), lds, st, attn_args(d));
+    if (d->dtable) {
+        float* full = d->dbias_ws + (size_t)nbw * d->nh * WT * WT;
+        hipLaunchKernelGGL(dbias_sum_kernel, dim3((d->nh * WT * WT + 255) / 256), dim3(256), 0, st, d->dbias_ws, nbw, d->nh, full);
+        hipLaunchKernelGGL(dbias_table_kernel, dim3(((2 * WS - 1) * (2 * WS - 1) * d->nh + 255) / 256), dim3(256), 0, st, full, d->nh, d->dtable,
+                           d->accumulate_dtable);
+    }
+    return tr::launch_status("tr_window_attention_bwd");
+}
+
+extern "C" int tr_pixel_shuffle(void* stream, tr_view in, tr_view out, int n, int h, int w, int c, int r, int inverse) {
+    TR_REQUIRE(in.ptr && out.ptr && n > 0 && h > 0 && w > 0 && c > 0 && r >= 1, TR_EINVAL, "tr_pixel_shuffle: bad arguments");
+    TR_REQUIRE(inverse ? (in.c >= c && out.c >= c * r * r) : (in.c >= c * r * r && out.c >= c), TR_EINVAL, "tr_pixel_shuffle: views too narrow");
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((int64_t)n * h * w * c * r * r)), dim3(256), 0, (hipStream_t)stream, in, out, n, h, w, c, r,
+                       inverse);
+    return tr::launch_status("tr_pixel_shuffle");
+}

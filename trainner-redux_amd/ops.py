@@ -177,6 +177,61 @@ def fold_replicate_nchw(gp: L.View, dst: torch.Tensor, ch_scale=None, accumulate
     L.check(L.lib().tr_fold_replicate_nchw(stream_ptr(), gp, dst.data_ptr(), n, c, h, w, sc, 1 if accumulate else 0), "tr_fold_replicate_nchw")
 
 
+def nhwc_to_nchw_affine(src_view: L.View, dst: torch.Tensor, scale, offset):
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 4
+    n, c, h, w = dst.shape
+    L.check(L.lib().tr_nhwc_to_nchw_affine(stream_ptr(), src_view, dst.data_ptr(), n, c, h, w, _f3(scale), _f3(offset)), "tr_nhwc_to_nchw_affine")
+
+
+def layernorm(x: L.View, y: L.View, ntok: int, c: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, mean: torch.Tensor | None = None,
+              rstd: torch.Tensor | None = None):
+    L.check(L.lib().tr_layernorm(stream_ptr(), x, y, ntok, c, gamma.data_ptr(), beta.data_ptr(), eps, mean.data_ptr() if mean is not None else None,
+                                 rstd.data_ptr() if rstd is not None else None), "tr_layernorm")
+
+
+def layernorm_bwd(g: L.View, x: L.View, ntok: int, c: int, gamma, mean, rstd, res: L.View, dx: L.View, dgamma, dbeta, workspace: torch.Tensor,
+                  accumulate=True):
+    L.check(L.lib().tr_layernorm_bwd(stream_ptr(), g, x, ntok, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), res, dx, dgamma.data_ptr(),
+                                     dbeta.data_ptr(), 1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+            "tr_layernorm_bwd")
+
+
+def layernorm_bwd_workspace_bytes(c: int) -> int:
+    return int(L.lib().tr_layernorm_bwd_workspace_bytes(c))
+
+
+def _attn_desc(qkv, table, b, h, w, c, nh, shift):
+    d = L.WindowAttnDesc()
+    d.qkv, d.table = qkv, table.data_ptr()
+    d.b, d.h, d.w, d.c, d.nh, d.window, d.shift = b, h, w, c, nh, 8, shift
+    d.scale = float((c // nh) ** -0.5)
+    return d
+
+
+def window_attention(qkv: L.View, out: L.View, table: torch.Tensor, *, b, h, w, c, nh, shift):
+    d = _attn_desc(qkv, table, b, h, w, c, nh, shift)
+    d.out = out
+    L.check(L.lib().tr_window_attention(stream_ptr(), C.byref(d)), "tr_window_attention")
+
+
+def window_attention_bwd_workspace_bytes(b, h, w, nh) -> int:
+    return int(L.lib().tr_window_attention_bwd_workspace_bytes(b, h, w, nh))
+
+
+def window_attention_bwd(qkv: L.View, dout: L.View, dqkv: L.View, table: torch.Tensor, dtable: torch.Tensor | None, workspace: torch.Tensor | None, *,
+                         b, h, w, c, nh, shift, accumulate=True):
+    d = _attn_desc(qkv, table, b, h, w, c, nh, shift)
+    d.dout, d.dqkv = dout, dqkv
+    d.dtable = dtable.data_ptr() if dtable is not None else None
+    d.dbias_ws = workspace.data_ptr() if (workspace is not None and dtable is not None) else None
+    d.accumulate_dtable = 1 if accumulate else 0
+    L.check(L.lib().tr_window_attention_bwd(stream_ptr(), C.byref(d)), "tr_window_attention_bwd")
+
+
+def pixel_shuffle(inp: L.View, out: L.View, n, h, w, c, r, inverse=False):
+    L.check(L.lib().tr_pixel_shuffle(stream_ptr(), inp, out, n, h, w, c, r, 1 if inverse else 0), "tr_pixel_shuffle")
+
+
 def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, mask: L.View | None = None, mask_slope: float = 0.2):
     L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix, mask if mask is not None else NULL_VIEW, mask_slope), "tr_axpby")
 
