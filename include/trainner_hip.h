@@ -177,9 +177,11 @@ int tr_nhwc_to_nchw_scaled(void* stream, tr_view src, float* dst, int n, int c_d
 /* dst[c] = src[c] * scale[c] + offset[c]  (SwinIR's `x / img_range + mean` on the way out; host pointers, 3 floats each) */
 int tr_nhwc_to_nchw_affine(void* stream, tr_view src, float* dst, int n, int c_dst, int h, int w, const float* scale3_host,
                            const float* offset3_host);
-/* out = (out.dtype)((a*sa + b*sb) * (mask > 0 ? 1 : mask_slope)) for NHWC views of equal shape (b and mask optional) --
- * residual / skip adds of activations and gradient streams, dtype conversion, LeakyReLU derivative of a skip branch */
-int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope);
+/* out = (out.dtype)((a*sa*s[p / pix_per_sample] + b*sb) * (mask > 0 ? 1 : mask_slope)) for NHWC views of equal shape
+ * (b, mask and the per-sample scale s optional) -- residual / skip adds of activations and gradient streams, dtype conversion,
+ * LeakyReLU derivative of a skip branch, DropPath keep mask on a gradient */
+int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope,
+             const float* sample_scale, int64_t pix_per_sample);
 /* adjoint of nn.Upsample(scale_factor=2, mode="nearest") (scunet_aaf6aa_arch.py:371): 2x2 sum pooling,
  * optionally times the LeakyReLU derivative taken from `mask` (the saved activation at low resolution) */
 int tr_sumpool2x2(void* stream, tr_view in, tr_view out, tr_view mask, float mask_slope, int n, int h_in, int w_in);

@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets")
+_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs")
 
 
 class FlatParamModule(nn.Module):

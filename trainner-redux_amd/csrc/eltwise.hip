@@ -42,13 +42,15 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(tr_view src, float* _
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, int c4, int va,
-                                                     int vb, int vout, tr_view mask, float mslope, int vm) {
+                                                     int vb, int vout, tr_view mask, float mslope, int vm, const float* __restrict__ sscale,
+                                                     int64_t pps) {
     const int64_t total = npix * c4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = i / c4;
         const int c = (int)(i - p * c4) * 4;
         float4 v = tr::view_load4(a, p, c, va);
-        v.x *= sa; v.y *= sa; v.z *= sa; v.w *= sa;
+        const float sa_ = sscale ? sa * sscale[p / pps] : sa;
+        v.x *= sa_; v.y *= sa_; v.z *= sa_; v.w *= sa_;
         if (b.ptr) {
             const float4 w = tr::view_load4(b, p, c, vb);
             v.x += sb * w.x; v.y += sb * w.y; v.z += sb * w.z; v.w += sb * w.w;
@@ -192,11 +194,13 @@ extern "C" int tr_nhwc_to_nchw_affine(void* stream, tr_view src, float* dst, int
     return tr::launch_status("tr_nhwc_to_nchw_affine");
 }
 
-extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope) {
+extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, tr_view out, int64_t npix, tr_view mask, float mask_slope,
+                        const float* sample_scale, int64_t pix_per_sample) {
     TR_REQUIRE(a.ptr && out.ptr && npix > 0 && a.c == out.c && a.c % 4 == 0 && (!b.ptr || b.c == a.c) && (!mask.ptr || mask.c == a.c), TR_EINVAL,
                "tr_axpby: views must have equal channel counts that are multiples of 4");
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(npix * (a.c / 4))), dim3(256), 0, (hipStream_t)stream, a, sa, b, sb, out, npix, a.c / 4,
-                       (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out), mask, mask_slope, (int)tr::view_vec4_ok(mask));
+                       (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out), mask, mask_slope, (int)tr::view_vec4_ok(mask),
+                       sample_scale, pix_per_sample > 0 ? pix_per_sample : npix);
     return tr::launch_status("tr_axpby");
 }
 

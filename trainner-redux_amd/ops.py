@@ -232,8 +232,10 @@ def pixel_shuffle(inp: L.View, out: L.View, n, h, w, c, r, inverse=False):
     L.check(L.lib().tr_pixel_shuffle(stream_ptr(), inp, out, n, h, w, c, r, 1 if inverse else 0), "tr_pixel_shuffle")
 
 
-def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, mask: L.View | None = None, mask_slope: float = 0.2):
-    L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix, mask if mask is not None else NULL_VIEW, mask_slope), "tr_axpby")
+def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, mask: L.View | None = None, mask_slope: float = 0.2,
+          sample_scale: torch.Tensor | None = None, pix_per_sample: int = 0):
+    L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix, mask if mask is not None else NULL_VIEW, mask_slope,
+                             sample_scale.data_ptr() if sample_scale is not None else None, pix_per_sample), "tr_axpby")
 
 
 def space_to_depth2(inp: L.View, out: L.View, n, h, w):
