@@ -34,14 +34,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
-    ap.add_argument("--lq", type=int, default=256, help="LR tile size")
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s"],
+                    help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan, 32 for swinir)")
+    ap.add_argument("--lq", type=int, default=None, help="LR tile size (default 256 for esrgan, 64 for swinir)")
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    return ap.parse_args()
+    args = ap.parse_args()
+    swin = args.arch != "esrgan"
+    args.batch = args.batch or (32 if swin else 16)
+    args.lq = args.lq or (64 if swin else 256)
+    if swin and args.losses != "l1":
+        args.losses = "l1"            # configs[3] names no perceptual head; the reference's SwinIR template trains on a pixel loss
+    return args
 
 
 def make_opt(args):
@@ -54,7 +62,7 @@ def make_opt(args):
         losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
     return parse_options_dict(dict(
         name="bench", scale=4, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute == "bf16", amp_bf16=True,
-        network_g=dict(type="esrgan", num_blocks=args.blocks),
+        network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=4),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
                    optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
@@ -83,13 +91,12 @@ class ConvTimer:
             orig(**kw)
             e1.record()
             cd = "bf16" if kw["compute"] == L.BF16 else "f32"
-            flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * 9 * kw["cin"] * kw["cout"]
-            timer.records.append(((cd, 64 if kw["cout"] > 32 else 32), flops, e0, e1))
+            ks = kw.get("ksize", 3)
+            flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * ks * ks * kw["cin"] * kw["cout"]
+            timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1))
 
         ops.conv3x3 = timed
-        import trainner_redux_amd.archs.rrdbnet_arch as ra
-
-        ra.ops = ops  # same module object; attribute lookups go through ops.conv3x3
+        # archs call `ops.conv3x3(...)` through the module attribute, so the wrapper is seen everywhere
 
     def summary(self):
         agg = {}
@@ -122,12 +129,18 @@ def cpu_baseline(args, perceptual: bool):
     """Oracle step on the host cores: 1 image, 64 -> 256 tile = 1/16 of the pixels of one 256 -> 1024 image."""
     from collections import OrderedDict
 
-    from oracle import esrgan as OE, losses as OL, step as OS, vgg as OV
+    from oracle import esrgan as OE, losses as OL, step as OS, swinir as OW, vgg as OV
 
     threads = host_threads()
     torch.set_num_threads(threads)
-    hp = OE.esrgan_hparams(scale=4, num_blocks=args.blocks)
-    sd = OE.init_state_dict(hp, 0)
+    if args.arch == "esrgan":
+        hp = OE.esrgan_hparams(scale=4, num_blocks=args.blocks)
+        sd = OE.init_state_dict(hp, 0)
+        fwd = lambda p, x: OE.forward(p, x, hp)  # noqa: E731
+    else:
+        hp = OW.hparams(args.arch, scale=4)
+        sd = OW.init_state_dict(hp, 0)
+        fwd = lambda p, x: OW.forward(p, x, hp)  # noqa: E731
     params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
     st = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
     ema = OS.EMAState(OrderedDict((k, v.data) for k, v in params.items()), beta=0.999, power=0.75)
@@ -139,7 +152,6 @@ def cpu_baseline(args, perceptual: bool):
     if perceptual:
         vsd = OV.synthetic_state_dict(0)
         fns["l_g_perceptual"] = (lambda o, t: OV.perceptual_loss(vsd, o, t), 0.01)
-    fwd = lambda p, x: OE.forward(p, x, hp)  # noqa: E731
     OS.generator_step(params, fwd, fns, lq, gt, st, ema)  # warm-up
     t0 = time.perf_counter()
     reps = 0
@@ -223,12 +235,12 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": "training images/sec (256->1024 4x SR) ESRGAN",
+            "metric": f"training images/sec ({s}->{4 * s} 4x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SwinIR"),
             "value": n * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"ESRGAN 4x (RRDBNet {args.blocks} blocks) {args.losses} {args.compute}, {s}->{4 * s} tiles, "
-                                   f"batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+            "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"SwinIR 4x ({args.arch})")
+                                   + f" {args.losses} {args.compute}, {s}->{4 * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }
@@ -241,15 +253,15 @@ def main():
             traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
-                    traffic = tj[f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"]
+                if args.arch == "esrgan" and tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
+                    traffic = tj[f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"] if key[2] == 3 else None
             except Exception:
                 traffic = None
-            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}>", "achieved": ach, "peak": peak,
+            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}, ksize {key[2]}>", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops / cnt, "launches": cnt,
                                "avg_launch_ms": msum / cnt,
                                "share_of_step": msum / (dt * 1e3),
-                               "all": {f"{k[0]}/cg{k[1]}": {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
+                               "all": {f"{k[0]}/cg{k[1]}" + ("" if k[2] == 3 else f"/k{k[2]}"): {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
         if not args.no_cpu_baseline and world == 1:
             log(f"cpu baseline on {host_threads()} threads")
             out["cpu_baseline"] = cpu_baseline(args, "perceptual" in args.losses)

@@ -236,3 +236,18 @@ def test_ema_schedule_matches_oracle():
         ema.update()
         ora.update(OrderedDict(w=lin.weight.data))
         assert torch.allclose(ema.ema_model.weight, ora.shadow["w"], atol=1e-7)
+
+
+def test_mfma_kernels_keep_accumulators_in_registers():
+    """The compiler's own resource report (written by build.py): no MFMA kernel may use scratch memory -- an accumulator array
+    demoted to scratch (a rolled loop indexing it) costs 10x and is invisible to the parity tests."""
+    import json
+
+    from trainner_redux_amd import build as B
+
+    B.build(verbose=False)
+    res = json.load(open(B.RESOURCES))
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn"))}
+    assert len(hot) >= 20
+    bad = {k: v["scratch"] for k, v in hot.items() if v.get("scratch", 0) != 0 or v.get("vgpr_spill", 0) != 0}
+    assert not bad, bad

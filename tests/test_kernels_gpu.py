@@ -368,7 +368,8 @@ def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
 
 
 @pytest.mark.parametrize("compute_name", ["f32", "bf16"])
-@pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180)])
+@pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180), (2, 18, 32, 192, 540), (1, 8, 32, 192, 256),
+                                  (1, 6, 32, 192, 300), (2, 16, 32, 192, 360), (1, 9, 32, 64, 120), (1, 8, 48, 64, 60), (2, 5, 32, 64, 24)])
 def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     """nn.Linear over tokens (drct_arch.py:64-66,166-168) = the MFMA kernel with ksize 1 on an n x h x 32 token grid:
     forward with exact GELU (+ pre-activation side output), input gradient with the GELU-derivative mask, weight/bias gradient."""
@@ -409,7 +410,7 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     ops.conv3x3(n=n, h=h, w=w, cin=kp, cout=nout, compute=compute, inp=ops.view(xd), out=ops.view(out), out2=ops.view(pre_d), wpacked=slab, bias=bd,
                 act=L.ACT_GELU, ksize=1, sample_scale=keepd)
     assert rel_l2(out[..., :nout].reshape(-1, nout).cpu(), y.detach()) < 3e-6
-    assert out[..., nout:].abs().max().item() == 0
+    assert nop == nout or out[..., nout:].abs().max().item() == 0
     tolp = 3e-6 if compute == L.F32 else 3e-3
     assert rel_l2(pre_d[..., :nout].float().reshape(-1, nout).cpu(), pre.detach()) < tolp
     # input gradient: dX = (gy * keep * gelu'(pre)) @ W ; the mask/keep are applied by a preceding axpby-like op in the net, here on the host

@@ -14,14 +14,14 @@ def rel_l2(a, b):
     return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
 
 
-def _opt(losses, accum=1, network_d=None, optim_d=None, use_amp=False, grad_clip=False, blocks=2):
+def _opt(losses, accum=1, network_d=None, optim_d=None, use_amp=False, grad_clip=False, blocks=2, network_g=None):
     from trainner_redux_amd.utils.options import parse_options_dict
 
     train = dict(total_iter=100, ema_decay=0.999, ema_power=0.75, grad_clip=grad_clip,
                  optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]), losses=losses)
     if optim_d:
         train["optim_d"] = optim_d
-    d = dict(name="t", scale=4, num_gpu=1, path={}, use_amp=use_amp, amp_bf16=True, network_g=dict(type="esrgan", num_blocks=blocks),
+    d = dict(name="t", scale=4, num_gpu=1, path={}, use_amp=use_amp, amp_bf16=True, network_g=network_g or dict(type="esrgan", num_blocks=blocks),
              datasets=dict(train=dict(name="x", type="pairedimagedataset", accum_iter=accum)), train=train)
     if network_d:
         d["network_d"] = network_d
@@ -166,3 +166,31 @@ def test_bf16_step_and_foreign_loss_head(cuda):
     assert model.output.shape == gt.shape
     model.test()
     assert model.output.shape == gt.shape
+
+
+def test_swinir_step_matches_oracle(cuda):
+    """SwinIR generator behind the same trainer: one L1 + Charbonnier step (fp32, DropPath off) against the oracle's step."""
+    from oracle import losses as OL, step as OS, swinir as OW
+    from trainner_redux_amd.models import SRModel
+
+    over = dict(scale=4, depths=[2, 2], num_heads=[6, 6], drop_path_rate=0.0)
+    model = SRModel(_opt([dict(type="l1loss", loss_weight=1.0), dict(type="charbonnierloss", loss_weight=0.5)],
+                         network_g=dict(type="swinir_s", **over)))
+    hp = OW.hparams("swinir_s", **over)
+    sd = OW.init_state_dict(hp, 0)
+    model.net_g.load_state_dict(sd, strict=False)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    oema = OS.EMAState(OrderedDict((k, v.data) for k, v in params.items()), beta=0.999, power=0.75)
+    fns = OrderedDict(l_g_l1=(OL.l1, 1.0), l_g_charbonnier=(OL.charbonnier, 0.5))
+    lq, gt = _data(seed=5)
+    _, ld, _, _ = OS.generator_step(params, lambda p, x: OW.forward(p, x, hp), fns, lq, gt, ost, oema)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    for k in ("l_g_l1", "l_g_charbonnier", "l_g_total"):
+        assert abs(log[k] - float(ld[k])) < 1e-5 * abs(float(ld[k])), (k, log[k], float(ld[k]))
+    sdm = model.net_g.state_dict()
+    e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in params.items())
+    print("swinir weights after one step", e_w)
+    assert e_w < 5e-4       # AdamW first-step sign sensitivity, as above

@@ -112,7 +112,7 @@ __device__ __forceinline__ float gelu_grad(float x) {   // d/dx [x * Phi(x)], ex
 // segment): residual / mask loads and the stores become 8-16 B per lane over contiguous pixel records.
 template <int NT, int R>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
-                                              int l, bool wave_active) {
+                                              int l, bool wave_active, int strip_id = -1) {
     constexpr int CGW = NT * 32;
     constexpr int ROWB = CGW * 4 + 16;
     constexpr int SEGS = CGW / 4;            // 16-byte fp32 segments per pixel
@@ -120,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
     __syncthreads();                          // every wave is done with the staged operands: LDS is free
     if (!wave_active || (a.dbg & 4)) return;
     const int lr = l & 31, lh = l >> 5;
-    char* strip = smem + wv * (32 * ROWB);
+    char* strip = smem + (strip_id < 0 ? wv : strip_id) * (32 * ROWB);   // wv: row group of the tile; strip_id: wave (when they differ)
     const bool generic = !(a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_res2 && a.vec_mask);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -134,7 +134,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                     make_float4(acc[r][t][q * 4 + 0], acc[r][t][q * 4 + 1], acc[r][t][q * 4 + 2], acc[r][t][q * 4 + 3]);
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
+        // a rolled loop on purpose: the body (erf GELU, derivative mask, generic tails) is large, and unrolling it ITER x R times
+        // pushes the kernel past the unroll budget -- the r loop then stays rolled and `acc` is demoted to scratch memory
+#pragma unroll 1
         for (int i = 0; i < ITER; ++i) {
             const int idx = i * 64 + l;
             const int p = idx / SEGS, seg = idx - p * SEGS;
@@ -491,6 +493,99 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
     return tr::launch_status("tr_conv3x3");
 }
 
+
+// ---- Linear layers: ksize 1 on a 32-wide token grid, as a GEMM with up to 192 output channels per workgroup ---------------------
+// A 1x1 "conv" has no tap reuse: with the 3x3 tiling (one 64-channel group per workgroup) the token rows are re-read by every
+// output group and the kernel runs at L2 speed (measured 37 TFLOP/s on SwinIR's qkv/proj/fc1/fc2).  Here a workgroup owns
+// 128 tokens x NCG 64-channel groups of the SAME packed slab: 2 x 2 waves, each 64 tokens x NCG*32 channels (2 x NCG MFMA tiles),
+// so the token tile is fetched cout/192 times instead of cout/64 and each LDS operand read feeds 1.2-1.5 MFMAs.  Register-staged
+// prefetch of the next K-chunk, 2-3 workgroups per CU; same MFMA chunk routine and fused epilogue as the 3x3 kernel.  Workgroup
+// ids are dealt so that the workgroups sharing a token tile sit on one XCD (ids round-robin over the 8 XCDs) and share its L2.
+template <int CT, int NCG>
+__global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(ConvArgs a, int nblk) {
+    constexpr int R = 2, NT = NCG;
+    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int EPS = 16 / ES;
+    constexpr int CK = 64 / ES;
+    constexpr int X_BYTES = 128 * 64;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* hl = smem;
+    char* wl = smem + X_BYTES;
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wv = tid >> 6;
+    const int lr = l & 31, lh = l >> 5;
+    const int wr = wv >> 1, wc = wv & 1;
+
+    const int total = nblk * a.nty * a.n;
+    const int per = (total + 7) >> 3;
+    int t_ = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t_ >= total) return;
+    const int cb = t_ % nblk; t_ /= nblk;
+    const int y0 = (t_ % a.nty) * 4;
+    const int nb = t_ / a.nty;
+
+    const int s_slot = tid & 3, pp0 = tid >> 2;
+    const int lds0 = pp0 * 64 + ((s_slot ^ ((pp0 >> 2) & 3)) << 4);
+    const int64_t pixb = (int64_t)a.in.cstride * ES;
+    const char* src0 = (const char*)a.in.ptr + (int64_t)(a.in.coff + s_slot * EPS) * ES + (((int64_t)nb * a.h + y0) * 32 + pp0) * pixb;
+    const bool rowok0 = (y0 + (pp0 >> 5)) < a.h, rowok1 = (y0 + (pp0 >> 5) + 2) < a.h;
+    const char* wsrc0 = a.wpacked + (int64_t)(cb * NCG) * a.nchunks * 4096 + tid * 16;
+
+    uint4 xreg[2], wreg[NCG];
+#define TR_LIN_ISSUE(CH)                                                                                                \
+    {                                                                                                                   \
+        const bool cvalid = (((CH) * CK + s_slot * EPS) < a.cin) && !(a.dbg & 2);                                       \
+        xreg[0] = make_uint4(0, 0, 0, 0);                                                                                \
+        xreg[1] = make_uint4(0, 0, 0, 0);                                                                                \
+        if (cvalid && rowok0) xreg[0] = *(const uint4*)(src0 + (int64_t)(CH) * 64);                                      \
+        if (cvalid && rowok1) xreg[1] = *(const uint4*)(src0 + (int64_t)(CH) * 64 + 64 * pixb);                          \
+        _Pragma("unroll") for (int g = 0; g < NCG; ++g) {                                                                \
+            wreg[g] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (cb * NCG + g < a.ncg && !(a.dbg & 2)) wreg[g] = *(const uint4*)(wsrc0 + ((int64_t)g * a.nchunks + (CH)) * 4096); \
+        }                                                                                                               \
+    }
+
+    f32x16 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+    const bool wave_active = (y0 + wr * R) < a.h;
+    TR_LIN_ISSUE(0)
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        __syncthreads();
+        *(uint4*)(hl + lds0) = xreg[0];
+        *(uint4*)(hl + lds0 + 4096) = xreg[1];
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) *(uint4*)(wl + g * 4096 + tid * 16) = wreg[g];
+        __syncthreads();
+        if (ch + 1 < a.nchunks) TR_LIN_ISSUE(ch + 1)
+        if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R, 1>(hl, wl + wc * (NCG * 32 * 64), acc, wr, lr, lh);
+    }
+#undef TR_LIN_ISSUE
+    conv_epilogue<NT, R>(a, acc, smem, nb, y0, 0, cb * 2 + wc, wr, l, wave_active, wv);
+}
+
+template <int CT, int NCG>
+int launch_linear(hipStream_t st, const ConvArgs& a, int nblk) {
+    constexpr size_t stage = 128 * 64 + (size_t)NCG * 4096;
+    constexpr size_t strips = (size_t)4 * 32 * (NCG * 32 * 4 + 16);
+    constexpr size_t lds = stage > strips ? stage : strips;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)linear_kernel<CT, NCG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int total = nblk * a.nty * a.n;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    hipLaunchKernelGGL((linear_kernel<CT, NCG>), dim3(grid), dim3(NTHREADS), lds, st, a, nblk);
+    return tr::launch_status("tr_conv3x3(linear)");
+}
+
 template <int CT, int NT, int R>
 int launch_dma(hipStream_t st, const ConvArgs& a, int ncg) {
     constexpr int halo_it = ((4 * R + 2) * HALO_W * 4 + NTHREADS - 1) / NTHREADS;
@@ -582,6 +677,16 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
     const bool big = g.cgw == 32 && (force_r ? force_r == 4 : roomy);
     const bool bf = d->compute == TR_BF16;
+    static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
+    if (d->ksize == 1 && d->w == 32 && g.cgw == 64 && !no_linear) {
+        // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
+        const int ncgb = g.ncg == 4 ? 2 : (g.ncg < 3 ? g.ncg : 3);
+        const int nblk = (g.ncg + ncgb - 1) / ncgb;
+        a.nty = (d->h + 3) / 4;
+        if (ncgb == 3) return bf ? launch_linear<TR_BF16, 3>(st, a, nblk) : launch_linear<TR_F32, 3>(st, a, nblk);
+        if (ncgb == 2) return bf ? launch_linear<TR_BF16, 2>(st, a, nblk) : launch_linear<TR_F32, 2>(st, a, nblk);
+        return bf ? launch_linear<TR_BF16, 1>(st, a, nblk) : launch_linear<TR_F32, 1>(st, a, nblk);
+    }
     if (d->ksize == 1) {
         if (big) {
             a.nty = (d->h + 15) / 16;
