@@ -6,7 +6,8 @@
               weight; in backward also the incoming gradient) to bfloat16 and accumulates in fp32,
               which is the arithmetic contract of the HIP bf16 path (DESIGN.md section "numerics").
               Everything outside the contraction (bias, LeakyReLU, residual adds, loss, AdamW)
-              stays fp32.  This is *more* precise than the reference's own AMP path
+              stays fp32.  The same holds for the attention matmuls (q k^T and P v): operands bf16, scores /
+              softmax / accumulation fp32.  This is *more* precise than the reference's own AMP path
               (autocast also rounds conv outputs and residual adds to bf16,
               /root/reference/traiNNer/models/sr_model.py:474-478).
 """
@@ -40,6 +41,23 @@ class _ConvBf16Ops(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+class _MatmulBf16Ops(torch.autograd.Function):
+    """a @ b with both operands bf16-rounded (fp32 accumulate); the backward contractions round the incoming gradient too
+    (window attention on MFMA: q, k, v, P, dO, dS are the bf16 operands, trainner-redux_amd/csrc/attn_mfma.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ar, br = _r(a), _r(b)
+        ctx.save_for_backward(ar, br)
+        return ar @ br
+
+    @staticmethod
+    def backward(ctx, g):
+        ar, br = ctx.saved_tensors
+        gr = _r(g)
+        return gr @ br.transpose(-2, -1), ar.transpose(-2, -1) @ gr
+
+
 class Policy:
     def __init__(self, name: str) -> None:
         if name not in ("fp32", "bf16_ops"):
@@ -50,6 +68,11 @@ class Policy:
         if self.name == "fp32":
             return F.conv2d(x, w, b, stride=stride, padding=padding)
         return _ConvBf16Ops.apply(x, w, b, stride, padding)
+
+    def matmul(self, a, b):
+        if self.name == "fp32":
+            return a @ b
+        return _MatmulBf16Ops.apply(a, b)
 
 
 FP32 = Policy("fp32")

@@ -129,8 +129,13 @@ def block(sd, p, x, h, w, C, nh, ws, shift, policy, keep=None):
         t = torch.roll(t, (-shift, -shift), (1, 2))
     win = t.view(B, h // ws, ws, w // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
     qkv = _linear(policy, win, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(-1, ws * ws, 3, nh, C // nh).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * (C // nh) ** -0.5, qkv[1], qkv[2]
-    attn = q @ k.transpose(-2, -1)
+    scale = (C // nh) ** -0.5
+    if policy.name == "fp32":
+        q, k, v = qkv[0] * scale, qkv[1], qkv[2]          # the reference order: q * scale, then q @ k^T (drct_arch.py:188-190)
+        attn = q @ k.transpose(-2, -1)
+    else:
+        q, k, v = qkv[0], qkv[1], qkv[2]                  # bf16 operands as stored; the (non power-of-two) scale is applied in fp32
+        attn = policy.matmul(q, k.transpose(-2, -1)) * scale
     bias = sd[p + "attn.relative_position_bias_table"][rel_index(ws).view(-1)].view(ws * ws, ws * ws, nh).permute(2, 0, 1)
     attn = attn + bias.unsqueeze(0)
     if shift:
@@ -138,7 +143,7 @@ def block(sd, p, x, h, w, C, nh, ws, shift, policy, keep=None):
         nW = m.shape[0]
         attn = (attn.view(B, nW, nh, ws * ws, ws * ws) + m.unsqueeze(1).unsqueeze(0)).view(-1, nh, ws * ws, ws * ws)
     attn = attn.softmax(-1)
-    o = (attn @ v).transpose(1, 2).reshape(-1, ws * ws, C)
+    o = policy.matmul(attn, v).transpose(1, 2).reshape(-1, ws * ws, C)
     o = _linear(policy, o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
     o = o.view(B, h // ws, w // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, C)
     if shift:

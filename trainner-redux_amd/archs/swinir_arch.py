@@ -284,7 +284,7 @@ class SwinIR(FlatParamModule):
             ln1 = Z(B, h, w, CP)
             s["m1"], s["r1"] = torch.empty(T, device=dev), torch.empty(T, device=dev)
             ops.layernorm(V(x_in, 0, C), V(ln1), T, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, s["m1"], s["r1"])
-            qkv = Z(B, h, w, C3P, dt=f32)
+            qkv = Z(B, h, w, C3P)                    # compute dtype: bf16 q, k, v are the MFMA operands of attn_mfma.hip
             ops.conv3x3(cin=CP, cout=3 * C, inp=V(ln1), out=V(qkv), wpacked=st[("qkv", i, j)][0], bias=blk.attn.qkv.bias.data, **tg)
             ao = Z(B, h, w, CP)
             ops.window_attention(V(qkv), V(ao), blk.attn.relative_position_bias_table.data, b=B, h=h, w=w, c=C, nh=nh, shift=blk.shift)
@@ -423,7 +423,7 @@ class SwinIR(FlatParamModule):
         keepm = sv["keep"]
         blocks = list(self._blocks())
         gcd, g_pre, dqkv = Z(B, h, w, CP), Z(B, h, w, HP), Z(B, h, w, C3P)
-        g_ln, g_ao = Z(B, h, w, CP, dt=f32), Z(B, h, w, CP, dt=f32)
+        g_ln, g_ao = Z(B, h, w, CP, dt=f32), Z(B, h, w, CP)
         g_layer_out = None
         for i, j, nh, blk in reversed(blocks):
             s = sv["blocks"][(i, j)]

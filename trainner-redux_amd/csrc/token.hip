@@ -10,10 +10,11 @@
 // registers, so the softmax max/sum are lane-local (no cross-lane traffic at all); K and V sit in LDS and are read as broadcasts.
 // The contractions here are 6 % of SwinIR's FLOPs and run on the VALU in fp32; the Linear layers
 // (71 %) and convs (22 %) are on MFMA (conv3x3.hip, ksize 1 / 3).
-#include "common.h"
+#include "attn.h"
 
 namespace {
 
+using tr::AttnArgs;
 constexpr int WS = 8, WT = 64, HDMAX = 32;
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -115,15 +116,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* 
 }
 
 // ---- window attention ----------------------------------------------------------------------------------------------------
-struct AttnArgs {
-    tr_view qkv, out;          // forward: qkv (fp32 or bf16, [q | k | v] x heads x hd), out = attention output (C channels)
-    tr_view dout, dqkv;        // backward
-    const float* table;        // (2*WS-1)^2 x nh
-    float* dbias_ws;           // backward: [b*nW + win][nh][64][64]
-    int b, h, w, nh, hd, c, shift;
-    float scale;
-};
-
 __device__ __forceinline__ int region(int s, int n, int shift) { return s < n - WS ? 0 : (s < n - shift ? 1 : 2); }
 
 // score row of query i against the 64 keys in LDS, + relative-position bias + shift mask; returns row max
@@ -373,12 +365,15 @@ extern "C" int tr_window_attention(void* stream, const tr_window_attn_desc* d) {
     int rc = attn_check(d);
     if (rc) return rc;
     TR_REQUIRE(d->out.ptr && d->out.c >= d->c, TR_EINVAL, "tr_window_attention: output view too narrow");
+    if (tr::attn_mfma_ok(attn_args(d), false)) return tr::launch_window_attn_fwd_mfma((hipStream_t)stream, attn_args(d));
     const int nblk = d->b * (d->h / WS) * (d->w / WS) * d->nh;
     hipLaunchKernelGGL(window_attn_fwd_kernel, dim3(nblk), dim3(64), 0, (hipStream_t)stream, attn_args(d));
     return tr::launch_status("tr_window_attention");
 }
 extern "C" size_t tr_window_attention_bwd_workspace_bytes(int b, int h, int w, int nh) {
-    return ((size_t)b * (h / WS) * (w / WS) * nh + (size_t)nh) * WT * WT * sizeof(float);
+    const size_t valu = ((size_t)b * (h / WS) * (w / WS) * nh + (size_t)nh) * WT * WT;            // per-window dS (fp32 path)
+    const size_t mfma = tr::window_attn_bwd_mfma_workspace_floats(b * (h / WS) * (w / WS) * nh, nh);  // per-wave sums (bf16 path)
+    return (valu > mfma ? valu : mfma) * sizeof(float);
 }
 extern "C" int tr_window_attention_bwd(void* stream, const tr_window_attn_desc* d) {
     int rc = attn_check(d);
@@ -386,6 +381,7 @@ extern "C" int tr_window_attention_bwd(void* stream, const tr_window_attn_desc* 
     TR_REQUIRE(d->dout.ptr && d->dqkv.ptr && d->dqkv.c >= 3 * d->c && d->dout.c >= d->c, TR_EINVAL, "tr_window_attention_bwd: gradient views too narrow");
     TR_REQUIRE((d->dtable == nullptr) == (d->dbias_ws == nullptr), TR_EINVAL, "tr_window_attention_bwd: dtable and dbias_ws come together");
     hipStream_t st = (hipStream_t)stream;
+    if (tr::attn_mfma_ok(attn_args(d), true)) return tr::launch_window_attn_bwd_mfma(st, attn_args(d), d->dtable, d->accumulate_dtable);
     const int nbw = d->b * (d->h / WS) * (d->w / WS);
     const size_t lds = (size_t)(4 * WT * (HDMAX + 1) + 2 * WT * (WT + 1)) * sizeof(float);
     static bool attr_set = false;
