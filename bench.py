@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s"],
                     help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles)")
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan, 32 for swinir)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan = configs[1], 8 for swinir = configs[3] / SURVEY.md cfg4)")
     ap.add_argument("--lq", type=int, default=None, help="LR tile size (default 256 for esrgan, 64 for swinir)")
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     swin = args.arch != "esrgan"
-    args.batch = args.batch or (32 if swin else 16)
+    args.batch = args.batch or (8 if swin else 16)
     args.lq = args.lq or (64 if swin else 256)
     if swin and args.losses != "l1":
         args.losses = "l1"            # configs[3] names no perceptual head; the reference's SwinIR template trains on a pixel loss

@@ -227,6 +227,28 @@ class SwinIR(FlatParamModule):
             st["plan"] = plan.finalize()
         st["plan"].run()
 
+    # ------------------------------------------------------------------ buffers ------------------------------------------------
+    def _pool(self, phase: str, dev, cdt):
+        """Activation / gradient buffers are drawn in a fixed order every step, so the n-th request of a phase reuses the n-th
+        buffer of the previous step (no allocator traffic, no per-step memset).  Saved activations therefore belong to the LATEST
+        training forward: run its backward before the next forward of this module."""
+        pool = self._ws.setdefault(phase, [])
+        idx = [0]
+
+        def take(*shape, dt=cdt):
+            i = idx[0]
+            idx[0] += 1
+            if i < len(pool):
+                t = pool[i]
+                if t.shape == tuple(shape) and t.dtype == dt and t.device == dev:
+                    return t
+                del pool[i:]                        # geometry changed (another tile size / batch): rebuild from here on
+            t = torch.zeros(*shape, dtype=dt, device=dev)
+            pool.append(t)
+            return t
+
+        return take
+
     # ------------------------------------------------------------------ forward ------------------------------------------------
     def _keep_masks(self, b, dev):
         """DropPath (drct_arch.py:572-573): per block and sample, keep/(1-p) with p rising linearly over the blocks."""
@@ -257,7 +279,7 @@ class SwinIR(FlatParamModule):
         st = self._slabs
         V = ops.view
         f32 = torch.float32
-        Z = lambda *s, dt=cdt: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731  (zero: channel padding must read as 0)
+        Z = self._pool("fwd", dev, cdt)       # zeroed once: kernels write real channels only, so the channel padding keeps reading as 0
         if train and keep_masks is None and self.drop_path_rate > 0:
             keep_masks = self._keep_masks(B, dev)
         keep_masks = keep_masks or {}
@@ -269,7 +291,7 @@ class SwinIR(FlatParamModule):
         fea = Z(B, h, w, CP, dt=f32)
         ops.conv3x3(cin=8, cout=C, inp=V(x8), out=V(fea), wpacked=st["conv_first"][0], bias=self.conv_first.bias.data, **ig)
         xs = Z(B, h, w, CP, dt=f32)
-        pe_mean, pe_rstd = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        pe_mean, pe_rstd = Z(T, dt=f32), Z(T, dt=f32)
         pe = self.patch_embed.norm
         ops.layernorm(V(fea, 0, C), V(xs), T, C, pe.weight.data, pe.bias.data, 1e-5, pe_mean, pe_rstd)
         sv.update(x8=x8, fea=fea, pe=(pe_mean, pe_rstd))
@@ -282,7 +304,7 @@ class SwinIR(FlatParamModule):
             keep = keep_masks.get((i, j))
             s = {}
             ln1 = Z(B, h, w, CP)
-            s["m1"], s["r1"] = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            s["m1"], s["r1"] = Z(T, dt=f32), Z(T, dt=f32)
             ops.layernorm(V(x_in, 0, C), V(ln1), T, C, blk.norm1.weight.data, blk.norm1.bias.data, 1e-5, s["m1"], s["r1"])
             qkv = Z(B, h, w, C3P)                    # compute dtype: bf16 q, k, v are the MFMA operands of attn_mfma.hip
             ops.conv3x3(cin=CP, cout=3 * C, inp=V(ln1), out=V(qkv), wpacked=st[("qkv", i, j)][0], bias=blk.attn.qkv.bias.data, **tg)
@@ -292,7 +314,7 @@ class SwinIR(FlatParamModule):
             ops.conv3x3(cin=CP, cout=C, inp=V(ao), out=V(x_mid), wpacked=st[("proj", i, j)][0], bias=blk.attn.proj.bias.data, res1=V(x_in),
                         sample_scale=keep, **tg)
             ln2 = Z(B, h, w, CP)
-            s["m2"], s["r2"] = torch.empty(T, device=dev), torch.empty(T, device=dev)
+            s["m2"], s["r2"] = Z(T, dt=f32), Z(T, dt=f32)
             ops.layernorm(V(x_mid, 0, C), V(ln2), T, C, blk.norm2.weight.data, blk.norm2.bias.data, 1e-5, s["m2"], s["r2"])
             post, pre = Z(B, h, w, HP), Z(B, h, w, HP)
             ops.conv3x3(cin=CP, cout=self.hid, inp=V(ln2), out=V(post), out2=V(pre), wpacked=st[("fc1", i, j)][0], bias=blk.mlp.fc1.bias.data,
@@ -315,7 +337,7 @@ class SwinIR(FlatParamModule):
                 sv[("lconv_in", i)] = xcd
                 x_in = nxt
         lnf = Z(B, h, w, CP)
-        fm, fr = torch.empty(T, device=dev), torch.empty(T, device=dev)
+        fm, fr = Z(T, dt=f32), Z(T, dt=f32)
         ops.layernorm(V(x_in, 0, C), V(lnf), T, C, self.norm.weight.data, self.norm.bias.data, 1e-5, fm, fr)
         body = Z(B, h, w, CP)
         ops.conv3x3(cin=CP, cout=C, inp=V(lnf), out=V(body), wpacked=st["cab"][0], bias=self.conv_after_body.bias.data, res1=V(fea), **ig)
@@ -366,7 +388,7 @@ class SwinIR(FlatParamModule):
         st = self._slabs
         V = ops.view
         f32 = torch.float32
-        Z = lambda *s, dt=cdt: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+        Z = self._pool("bwd", dev, cdt)
         tg = dict(n=B, h=h * w // 32, w=32, compute=cd, ksize=1)
         ig = dict(n=B, h=h, w=w, compute=cd)
         r = self.scale
@@ -375,8 +397,8 @@ class SwinIR(FlatParamModule):
         for (hh, ww, ci, co, ks) in [(h * w // 32, 32, CP, 3 * C, 1), (h * w // 32, 32, HP, C, 1), (h * w // 32, 32, CP, self.hid, 1), (h, w, CP, C, 3),
                                      (h, w, 3, C, 3), (H, W, self.nf, 3, 3), (H // 2, W // 2, self.nf, 4 * self.nf, 3), (h, w, CP, r * r * 3, 3)]:
             need = max(need, ops.wgrad_workspace_bytes(B, hh, ww, ci, co, ks))
-        wg = torch.empty(need // 4 + 16, dtype=f32, device=dev)
-        aws = torch.empty(ops.window_attention_bwd_workspace_bytes(B, h, w, max(self.heads)) // 4, dtype=f32, device=dev)
+        wg = Z(need // 4 + 16, dt=f32)
+        aws = Z(ops.window_attention_bwd_workspace_bytes(B, h, w, max(self.heads)) // 4, dt=f32)
 
         def wgrad_conv(m, inp, gy, hh, ww, ks=3):
             ops.wgrad3x3(n=B, h=hh, w=ww, cin=m.cin, cout=m.cout, compute=cd, inp=inp, gy=gy, dw=m.weight.grad, db=m.bias.grad, workspace=wg,
@@ -416,7 +438,8 @@ class SwinIR(FlatParamModule):
         wgrad_conv(self.conv_after_body, V(sv["lnf"]), V(g_body), h, w)
         g_lnf = Z(B, h, w, CP, dt=f32)
         ops.conv3x3(cin=CP, cout=C, inp=V(g_body), out=V(g_lnf), wpacked=st["cab"][1], **ig)
-        gx = Z(B, h, w, CP, dt=f32)
+        free = [Z(B, h, w, CP, dt=f32) for _ in range(5)]      # fp32 gradient-stream buffers, recycled block after block (stream order)
+        gx = free.pop()
         fm, fr = sv["fnorm"]
         ops.layernorm_bwd(V(g_lnf, 0, C), V(sv["x_final"], 0, C), T, C, self.norm.weight.data, fm, fr, ops.NULL_VIEW, V(gx, 0, C), self.norm.weight.grad,
                           self.norm.bias.grad, wg)
@@ -434,7 +457,7 @@ class SwinIR(FlatParamModule):
                 g_layer_out = gx
                 ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T)
                 wgrad_conv(layer.conv, V(sv[("lconv_in", i)]), V(gcd), h, w)
-                gx = Z(B, h, w, CP, dt=f32)
+                gx = free.pop()
                 ops.conv3x3(cin=CP, cout=C, inp=V(gcd), out=V(gx), wpacked=st[("lconv", i)][1], **ig)
             # ---- MLP branch: x_out = x_mid + keep * fc2(gelu(fc1(LN2(x_mid))))
             ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T, sample_scale=keep, pix_per_sample=h * w)
@@ -442,9 +465,10 @@ class SwinIR(FlatParamModule):
             ops.conv3x3(cin=CP, cout=self.hid, inp=V(gcd), out=V(g_pre), wpacked=st[("fc2", i, j)][1], mask=V(s["pre"]), mask_mode=1, **tg)
             wgrad_lin(blk.mlp.fc1, V(s["ln2"]), V(g_pre))
             ops.conv3x3(cin=HP, cout=C, inp=V(g_pre), out=V(g_ln), wpacked=st[("fc1", i, j)][1], **tg)
-            g_mid = Z(B, h, w, CP, dt=f32)
+            g_mid = free.pop()
             ops.layernorm_bwd(V(g_ln, 0, C), V(s["x_mid"], 0, C), T, C, blk.norm2.weight.data, s["m2"], s["r2"], V(gx, 0, C), V(g_mid, 0, C),
                               blk.norm2.weight.grad, blk.norm2.bias.grad, wg)
+            free.append(gx)
             # ---- attention branch: x_mid = x_in + keep * proj(attn(qkv(LN1(x_in))))
             ops.axpby(V(g_mid), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T, sample_scale=keep, pix_per_sample=h * w)
             wgrad_lin(blk.attn.proj, V(s["ao"]), V(gcd))
@@ -456,12 +480,16 @@ class SwinIR(FlatParamModule):
             res = g_mid
             if j == 0:
                 # the layer input also feeds the RSTB skip
-                tmp = Z(B, h, w, CP, dt=f32)
+                tmp = free.pop()
                 ops.axpby(V(g_mid), 1.0, V(g_layer_out), 1.0, V(tmp), T)
+                free.append(g_layer_out)
                 res = tmp
-            g_in = Z(B, h, w, CP, dt=f32)
+            g_in = free.pop()
             ops.layernorm_bwd(V(g_ln, 0, C), V(s["x_in"], 0, C), T, C, blk.norm1.weight.data, s["m1"], s["r1"], V(res, 0, C), V(g_in, 0, C),
                               blk.norm1.weight.grad, blk.norm1.bias.grad, wg)
+            free.append(g_mid)
+            if res is not g_mid:
+                free.append(res)
             gx = g_in
         # patch_embed.norm, long skip, conv_first
         pe = self.patch_embed.norm

@@ -442,25 +442,24 @@ __global__ __launch_bounds__(256) void dbias_part_sum_kernel(const float* __rest
     full[(int64_t)chunk * stride + i] = (s0 + s1) + (s2 + s3);
 }
 // table_grad[idx][head] (+)= sum over (query, key) pairs with relative index idx, over the chunked sums (key-major storage)
-__global__ __launch_bounds__(256) void dbias_table_kq_kernel(const float* __restrict__ full, int nh, float* __restrict__ dtable, int accumulate) {
-    const int tdx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tdx >= NTAB * nh) return;
+__global__ __launch_bounds__(64) void dbias_table_kq_kernel(const float* __restrict__ full, int nh, float* __restrict__ dtable, int accumulate) {
+    // one wave per table entry: lane = (chunk, query row); fixed shuffle tree -> deterministic
+    const int tdx = blockIdx.x;
     const int idx = tdx / nh, head = tdx - idx * nh;
     const int dy = idx / (2 * WS - 1) - (WS - 1), dx = idx % (2 * WS - 1) - (WS - 1);   // qy - ky, qx - kx
+    const int chunk = threadIdx.x >> 3, qy = threadIdx.x & 7;
+    const int ky = qy - dy;
     float s = 0.f;
-    for (int chunk = 0; chunk < DB_CHUNKS; ++chunk) {
+    if (ky >= 0 && ky < WS) {
         const float* f = full + ((int64_t)chunk * nh + head) * (WT * WT);
-        for (int qy = 0; qy < WS; ++qy) {
-            const int ky = qy - dy;
-            if (ky < 0 || ky >= WS) continue;
-            for (int qx = 0; qx < WS; ++qx) {
-                const int kx = qx - dx;
-                if (kx < 0 || kx >= WS) continue;
-                s += f[(ky * WS + kx) * WT + (qy * WS + qx)];
-            }
+        for (int qx = 0; qx < WS; ++qx) {
+            const int kx = qx - dx;
+            if (kx >= 0 && kx < WS) s += f[(ky * WS + kx) * WT + (qy * WS + qx)];
         }
     }
-    dtable[tdx] = accumulate ? dtable[tdx] + s : s;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) dtable[tdx] = accumulate ? dtable[tdx] + s : s;
 }
 
 int grid_for_tasks(int ntasks, int nh) {
@@ -512,7 +511,8 @@ int launch_window_attn_bwd_mfma(hipStream_t st, const AttnArgs& a, float* dtable
     if (rc || !dtable) return rc;
     float* full = part + (size_t)grid * 4 * WT * WT;
     hipLaunchKernelGGL(dbias_part_sum_kernel, dim3((a.nh * WT * WT + 255) / 256, DB_CHUNKS), dim3(256), 0, st, part, grid * 4 / a.nh, a.nh, full);
-    hipLaunchKernelGGL(dbias_table_kq_kernel, dim3((NTAB * a.nh + 255) / 256), dim3(256), 0, st, full, a.nh, dtable, accumulate);
+    static_assert(DB_CHUNKS == 8, "dbias_table_kq_kernel maps 8 chunks x 8 query rows onto one wave");
+    hipLaunchKernelGGL(dbias_table_kq_kernel, dim3(NTAB * a.nh), dim3(64), 0, st, full, a.nh, dtable, accumulate);
     return tr::launch_status("tr_window_attention_bwd(mfma, bias)");
 }
 

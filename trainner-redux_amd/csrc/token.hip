@@ -25,6 +25,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- LayerNorm: one wave per token, lane owns channels lane, lane+64, ... ------------------------------------------------
 constexpr int LN_MAXK = 12;   // C <= 768
+constexpr int LN_BWD_BLOCKS = 1024;
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(tr_view x, tr_view y, int64_t ntok, int c, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float* __restrict__ mean_out,
@@ -59,60 +60,92 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(tr_view x, tr_view y
 }
 
 // dx = rstd * (a - mean_c(a) - xhat * mean_c(a * xhat)), a = g * gamma ;  out = (res ? res : 0) + dx
-// partial dgamma / dbeta per block -> partials[block][2][c]
+// partial dgamma / dbeta per block -> partials[block][2][c].  NK = ceil(c / 64) register slots per lane (templated: a runtime bound
+// would index the arrays dynamically); two tokens per wave iteration keep twice the loads in flight (the kernel is latency bound).
+template <int NK>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(tr_view g, tr_view x, int64_t ntok, int c, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, tr_view res,
                                                              tr_view dx, float* __restrict__ partials) {
-    __shared__ float sh[4][2][LN_MAXK * 64];
+    __shared__ float sh[4][2][NK * 64];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
-    float dg[LN_MAXK], db[LN_MAXK];
+    float dg[NK], db[NK], gm[NK];
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) dg[k] = db[k] = 0.f;
-    for (int64_t t = wave; t < ntok; t += nwaves) {
-        const float mu = mean[t], rs = rstd[t];
-        float a[LN_MAXK], xh[LN_MAXK];
-        float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < NK; ++k) {
+        dg[k] = db[k] = 0.f;
+        gm[k] = (l + 64 * k) < c ? gamma[l + 64 * k] : 0.f;
+    }
+    for (int64_t t0 = wave * 2; t0 < ntok; t0 += nwaves * 2) {
+        float a[2][NK], xh[2][NK], rs[2];
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        bool live[2];
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
-            const int ch = l + 64 * k;
-            if (ch < c) {
-                const float gv = tr::view_load(g, t, ch);
-                xh[k] = (tr::view_load(x, t, ch) - mu) * rs;
-                a[k] = gv * gamma[ch];
-                dg[k] += gv * xh[k];
+        for (int u = 0; u < 2; ++u) {
+            const int64_t t = t0 + u;
+            live[u] = t < ntok;
+            const float mu = live[u] ? mean[t] : 0.f;
+            rs[u] = live[u] ? rstd[t] : 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int ch = l + 64 * k;
+                float gv = 0.f, xv = 0.f;
+                if (live[u] && ch < c) { gv = tr::view_load(g, t, ch); xv = tr::view_load(x, t, ch); }
+                xh[u][k] = (live[u] && ch < c) ? (xv - mu) * rs[u] : 0.f;
+                a[u][k] = gv * gm[k];
+                dg[k] += gv * xh[u][k];
                 db[k] += gv;
-            } else { a[k] = 0.f; xh[k] = 0.f; }
-            s1 += a[k];
-            s2 += a[k] * xh[k];
+                s1[u] += a[u][k];
+                s2[u] += a[u][k] * xh[u][k];
+            }
         }
-        const float m1 = wave_sum(s1) / (float)c, m2 = wave_sum(s2) / (float)c;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
-            const int ch = l + 64 * k;
-            if (ch < c) {
-                float o = rs * (a[k] - m1 - xh[k] * m2);
-                if (res.ptr) o += tr::view_load(res, t, ch);
-                tr::view_store(dx, t, ch, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            s1[0] += __shfl_xor(s1[0], o, 64); s2[0] += __shfl_xor(s2[0], o, 64);
+            s1[1] += __shfl_xor(s1[1], o, 64); s2[1] += __shfl_xor(s2[1], o, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!live[u]) continue;
+            const int64_t t = t0 + u;
+            const float m1 = s1[u] / (float)c, m2 = s2[u] / (float)c;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int ch = l + 64 * k;
+                if (ch < c) {
+                    float o = rs[u] * (a[u][k] - m1 - xh[u][k] * m2);
+                    if (res.ptr) o += tr::view_load(res, t, ch);
+                    tr::view_store(dx, t, ch, o);
+                }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < LN_MAXK; ++k) { sh[wv][0][l + 64 * k] = dg[k]; sh[wv][1][l + 64 * k] = db[k]; }
+    for (int k = 0; k < NK; ++k) { sh[wv][0][l + 64 * k] = dg[k]; sh[wv][1][l + 64 * k] = db[k]; }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * c; i += blockDim.x) {
         const int which = i / c, ch = i - which * c;
         partials[(int64_t)blockIdx.x * 2 * c + i] = (sh[0][which][ch] + sh[1][which][ch]) + (sh[2][which][ch] + sh[3][which][ch]);
     }
 }
+// column sums of partials[nblocks][2c]: a block owns 32 columns, 8 row groups stride through the blocks, LDS tree at the end
 __global__ __launch_bounds__(256) void layernorm_bwd_finish_kernel(const float* __restrict__ partials, int nblocks, int c, float* __restrict__ dgamma,
                                                                     float* __restrict__ dbeta, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * c) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * 2 * c + i];
-    float* o = i < c ? dgamma + i : dbeta + (i - c);
-    *o = accumulate ? *o + s : s;
+    __shared__ float sh[8][32];
+    const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < 2 * c) {
+        int b = rg;
+        for (; b + 8 < nblocks; b += 16) { s0 += partials[(int64_t)b * 2 * c + i]; s1 += partials[(int64_t)(b + 8) * 2 * c + i]; }
+        if (b < nblocks) s0 += partials[(int64_t)b * 2 * c + i];
+    }
+    sh[rg][col] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && i < 2 * c) {
+        const float s = ((sh[0][col] + sh[1][col]) + (sh[2][col] + sh[3][col])) + ((sh[4][col] + sh[5][col]) + (sh[6][col] + sh[7][col]));
+        float* o = i < c ? dgamma + i : dbeta + (i - c);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 // ---- window attention ----------------------------------------------------------------------------------------------------
@@ -337,15 +370,19 @@ extern "C" int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok
                                 tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes) {
     TR_REQUIRE(g.ptr && x.ptr && dx.ptr && gamma && mean && rstd && dgamma && dbeta && partials && ntok > 0 && c > 0 && c <= LN_MAXK * 64, TR_EINVAL,
                "tr_layernorm_bwd: bad arguments");
-    int nb = (int)grid_for(ntok * 64, 512);
+    int nb = (int)grid_for(ntok * 32, LN_BWD_BLOCKS);      // a wave takes two tokens per iteration
     TR_REQUIRE(partials_bytes >= (size_t)nb * 2 * c * sizeof(float), TR_EINVAL, "tr_layernorm_bwd: workspace too small (need %zu bytes)",
                (size_t)nb * 2 * c * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials);
-    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * c + 255) / 256), dim3(256), 0, st, partials, nb, c, dgamma, dbeta, accumulate);
+    const int nk = (c + 63) / 64;
+#define TR_LN_BWD(NK) hipLaunchKernelGGL(layernorm_bwd_kernel<NK>, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials)
+    if (nk <= 1) TR_LN_BWD(1); else if (nk <= 2) TR_LN_BWD(2); else if (nk <= 3) TR_LN_BWD(3); else if (nk <= 4) TR_LN_BWD(4);
+    else if (nk <= 6) TR_LN_BWD(6); else if (nk <= 8) TR_LN_BWD(8); else TR_LN_BWD(12);
+#undef TR_LN_BWD
+    hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * c + 31) / 32), dim3(256), 0, st, partials, nb, c, dgamma, dbeta, accumulate);
     return tr::launch_status("tr_layernorm_bwd");
 }
-extern "C" size_t tr_layernorm_bwd_workspace_bytes(int c) { return (size_t)512 * 2 * c * sizeof(float); }
+extern "C" size_t tr_layernorm_bwd_workspace_bytes(int c) { return (size_t)LN_BWD_BLOCKS * 2 * c * sizeof(float); }
 
 static int attn_check(const tr_window_attn_desc* d) {
     TR_REQUIRE(d && d->qkv.ptr && d->table && d->b > 0 && d->h > 0 && d->w > 0 && d->nh > 0, TR_EINVAL, "tr_window_attention: bad arguments");
