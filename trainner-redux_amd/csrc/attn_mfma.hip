@@ -462,12 +462,15 @@ __global__ __launch_bounds__(64) void dbias_table_kq_kernel(const float* __restr
     if (threadIdx.x == 0) dtable[tdx] = accumulate ? dtable[tdx] + s : s;
 }
 
-int grid_for_tasks(int ntasks, int nh) {
+// workgroups (4 waves = 4 tasks in flight each): at most `cap` (one round of resident workgroups), a multiple of nh so that
+// waves * 4 % nh == 0 and every wave keeps its head across its tasks
+int grid_for_tasks(int ntasks, int nh, int cap) {
     int g = (ntasks + 3) / 4;
-    if (g > 512) g = 512;                 // two workgroups per CU; each wave then walks ~ntasks / 2048 windows of one head
-    g = (g + nh - 1) / nh * nh;           // waves * 4 must be a multiple of nh so that a wave keeps its head
+    if (g > cap) g = cap;
+    g = g >= nh ? g / nh * nh : nh;
     return g;
 }
+constexpr int FWD_CAP = 512, BWD_CAP = 256;      // resident workgroups: 2 per CU forward, 1 per CU backward (register budget)
 
 }  // namespace
 
@@ -488,12 +491,12 @@ bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
 int launch_window_attn_fwd_mfma(hipStream_t st, const AttnArgs& a) {
     const int ntasks = a.b * (a.h / WS) * (a.w / WS) * a.nh;
     const size_t lds = 4 * (size_t)(TILE + 1024);
-    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(grid_for_tasks(ntasks, a.nh)), dim3(256), lds, st, a, ntasks);
+    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(grid_for_tasks(ntasks, a.nh, FWD_CAP)), dim3(256), lds, st, a, ntasks);
     return tr::launch_status("tr_window_attention(mfma)");
 }
 
 size_t window_attn_bwd_mfma_workspace_floats(int ntasks, int nh) {
-    return ((size_t)grid_for_tasks(ntasks, nh) * 4 + (size_t)DB_CHUNKS * nh) * WT * WT;
+    return ((size_t)grid_for_tasks(ntasks, nh, BWD_CAP) * 4 + (size_t)DB_CHUNKS * nh) * WT * WT;
 }
 
 int launch_window_attn_bwd_mfma(hipStream_t st, const AttnArgs& a, float* dtable, int accumulate) {
@@ -504,7 +507,7 @@ int launch_window_attn_bwd_mfma(hipStream_t st, const AttnArgs& a, float* dtable
         hipFuncSetAttribute((const void*)window_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const int grid = grid_for_tasks(ntasks, a.nh);
+    const int grid = grid_for_tasks(ntasks, a.nh, BWD_CAP);
     float* part = dtable ? a.dbias_ws : nullptr;
     hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3(grid), dim3(256), lds, st, a, ntasks, part);
     int rc = tr::launch_status("tr_window_attention_bwd(mfma)");

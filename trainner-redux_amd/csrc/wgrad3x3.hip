@@ -241,11 +241,30 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
             }
 }
 
+// second stage of the two-stage reduction: blocks [0, nb_dw) sum the weight partials, blocks [nb_dw, gridDim.x) the bias partials
+// (per-slot column sums written by the (chunk 0, ky 0) waves) -- one launch for both
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
-                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps) {
+                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
+                                                            const float* __restrict__ db_partials, float* __restrict__ db) {
+    if ((int)blockIdx.x >= nb_dw) {
+        const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
+        if (co >= cout) return;
+        const int cg = co / cgw, col = co - cg * cgw;
+        const float* p = db_partials + (int64_t)cg * cgw + col;
+        const int64_t stride = (int64_t)ncg * cgw;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= nslots; k += 4) {
+            s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
+        }
+        for (; k < nslots; ++k) s0 += p[k * stride];
+        const float s = (s0 + s1) + (s2 + s3);
+        db[co] = accumulate ? db[co] + s : s;
+        return;
+    }
     // one thread per (co, tap, ci) with ci fastest so partial reads are coalesced
     const int64_t total = (int64_t)cout * taps * cin;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)nb_dw * blockDim.x) {
         const int ci = (int)(i % cin);
         const int tap = (int)((i / cin) % taps);
         const int co = (int)(i / ((int64_t)cin * taps));
@@ -264,24 +283,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         float* o = dw + ((int64_t)co * cin + ci) * taps + tap;
         *o = accumulate ? *o + s : s;
     }
-}
-
-// bias gradient: sum the per-slot column sums written by the (chunk 0, ky 0) waves
-__global__ __launch_bounds__(64) void db_finish_kernel(const float* __restrict__ partials, int nslots, int ncg, int cgw, int cout,
-                                                       float* __restrict__ db, int accumulate) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= cout) return;
-    const int cg = co / cgw, col = co - cg * cgw;
-    const float* p = partials + (int64_t)cg * cgw + col;
-    const int64_t stride = (int64_t)ncg * cgw;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int k = 0;
-    for (; k + 4 <= nslots; k += 4) {
-        s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
-    }
-    for (; k < nslots; ++k) s0 += p[k * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    db[co] = accumulate ? db[co] + s : s;
 }
 
 struct Plan {
@@ -376,15 +377,10 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
         const int64_t total = (int64_t)d->cout * taps * d->cin;
         int64_t b = (total + 255) / 256;
         if (b > 2048) b = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult, p.nchunks,
-                           p.ncg, p.cgw, d->accumulate, taps);
+        const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult,
+                           p.nchunks, p.ncg, p.cgw, d->accumulate, taps, (int)b, d->partials + p.dw_floats, d->db);
         rc = tr::launch_status("tr_wgrad3x3(reduce)");
-        if (rc) return rc;
-    }
-    if (d->db) {
-        hipLaunchKernelGGL(db_finish_kernel, dim3((d->cout + 63) / 64), dim3(64), 0, st, d->partials + p.dw_floats, p.nslots * (d->ksize == 1 ? 3 : 1), p.ncg, p.cgw,
-                           d->cout, d->db, d->accumulate);
-        rc = tr::launch_status("tr_wgrad3x3(bias finish)");
     }
     return rc;
 }
