@@ -27,9 +27,29 @@ def pmc(d, counter):
         a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     return agg
 
+def pmc_all(d):
+    """every counter of a --pmc pass, averaged per (kernel, grid size, LDS bytes)"""
+    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        key = (short(r["Kernel_Name"])[:48], r.get("Grid_Size", ""), r.get("LDS_Block_Size", ""))
+        agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[key]["_us"] += 0.0
+        cnt[key].add(r["Dispatch_Id"])
+        agg[key]["_t0"] = min(agg[key].get("_t0", 1e30) or 1e30, float(r["Start_Timestamp"]))
+    out = []
+    for key, cs in agg.items():
+        n = len(cnt[key])
+        names = [c for c in cs if not c.startswith("_")]
+        out.append(f"{key[0]:48s} grid {key[1]:>8s} lds {key[2]:>6s} launches {n:4d} | " + "  ".join(f"{c}={cs[c] / n:.3e}" for c in sorted(names)))
+    return "\n".join(out)
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    if cmd == "stats":
+    if cmd == "pmcall":
+        print(pmc_all(sys.argv[2]))
+    elif cmd == "stats":
         print(kernel_stats(sys.argv[2]))
     else:
         fe, wr = pmc(sys.argv[2], "FETCH_SIZE"), pmc(sys.argv[3], "WRITE_SIZE")

@@ -15,10 +15,12 @@
 //   * partials go to a caller workspace and a second kernel sums them in fixed slot order:
 //     bitwise reproducible, no float atomics.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -151,50 +153,61 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
         if (tile + a.nslots < a.ntiles) TR_WG_ISSUE(tile + a.nslots)   // in flight during this tile's MFMAs
 
         if constexpr (CT == TR_BF16) {
+            // Software-pipelined over the 16 (row, 16-pixel half) steps of the tile: the transposing LDS reads of step s+1 are issued
+            // before the MFMAs of step s, and every address is ONE lane-constant base plus a compile-time offset (the loop is fully
+            // unrolled), so a step costs its MFMAs + 2*(NT+KS) ds_read_b64_tr_b16 and nothing else.  (The rolled version spent its
+            // issue slots on 25 pointer increments per iteration and waited for each read right before its MFMA.)
             const int li = l & 15, q = li >> 2, p = li & 3;
             const int i0 = ((l >> 4) & 1) * 16;
-#pragma unroll 2
-            for (int r = r_first; r < TH; r += r_step) {
+            const int gsw = GSWZ ? ((q >> 1) & 1) : 0;       // bit 1 of the pixel index comes from q alone (all other terms are multiples of 4)
+            const char* gb[2] = {gl + (8 * lh + q) * GPIX_BYTES + (i0 + 4 * p) * 2 + (gsw ? 64 : 0),
+                                 gl + (8 * lh + q) * GPIX_BYTES + (i0 + 4 * p) * 2 + (gsw ? 0 : 64)};
+            const char* xb = xl + (kyo * HALO_W + 8 * lh + q) * XPIX_BYTES + (i0 + 4 * p) * 2;
+            constexpr int NR = KS == 3 ? TH : (TH + 2) / 3;       // rows this wave walks
+            constexpr int NSTEP = NR * 2;
+#define TR_TRRD(PTR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(PTR))
+#define TR_WG_FRAGS(FA, FB, STEP)                                                                                       \
+    {                                                                                                                   \
+        const int r_ = KS == 3 ? ((STEP) >> 1) : ky + 3 * ((STEP) >> 1);                                                 \
+        const int kb_ = (STEP) & 1;                                                                                      \
+        const int go_ = (r_ * 32 + kb_ * 16) * GPIX_BYTES, xo_ = (r_ * HALO_W + kb_ * 16) * XPIX_BYTES;                  \
+        _Pragma("unroll") for (int t2 = 0; t2 < NT; ++t2) {                                                              \
+            const s16x4 lo = TR_TRRD(gb[t2] + go_), hi = TR_TRRD(gb[t2] + go_ + 4 * GPIX_BYTES);                         \
+            FA[t2] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                   \
+        }                                                                                                               \
+        _Pragma("unroll") for (int kx = 0; kx < KS; ++kx) {                                                              \
+            const s16x4 lo = TR_TRRD(xb + xo_ + kx * XPIX_BYTES), hi = TR_TRRD(xb + xo_ + (kx + 4) * XPIX_BYTES);         \
+            FB[kx] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                                   \
+        }                                                                                                               \
+    }
+            bf16x8 fa[2][NT], fb[2][KS];
+            TR_WG_FRAGS(fa[0], fb[0], 0)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    bf16x8 af[NT];
+            for (int s = 0; s < NSTEP; ++s) {
+                if (KS == 1 && ky + 3 * (s >> 1) >= TH) break;       // 1x1: the three waves take interleaved rows
+                const int cur = s & 1;
+                if (s + 1 < NSTEP && (KS == 3 || ky + 3 * ((s + 1) >> 1) < TH)) TR_WG_FRAGS(fa[cur ^ 1], fb[cur ^ 1], s + 1)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2)
+                        acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][t2], fb[cur][kx], acc[kx][t2], 0, 0, 0);
+                if (do_bias) {
 #pragma unroll
                     for (int t2 = 0; t2 < NT; ++t2) {
-                        s16x4 lo, hi;
-                        {
-                            const int gp = r * 32 + kb * 16 + 8 * lh + q;
-                            int bo = (t2 * 32 + i0 + 4 * p) * 2;
-                            if (GSWZ) bo ^= ((gp >> 1) & 1) << 6;
-                            lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gl + gp * GPIX_BYTES + bo));
-                        }
-                        {
-                            const int gp = r * 32 + kb * 16 + 8 * lh + 4 + q;
-                            int bo = (t2 * 32 + i0 + 4 * p) * 2;
-                            if (GSWZ) bo ^= ((gp >> 1) & 1) << 6;
-                            hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gl + gp * GPIX_BYTES + bo));
-                        }
-                        af[t2] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        if (do_bias) {
-                            float sacc = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) sacc += tr::bf16_to_f32((unsigned short)af[t2][e]);
-                            bsum[t2] += sacc;
-                        }
-                    }
-#pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) {
-                        const int hp = (r + kyo) * HALO_W + kb * 16 + kx + 8 * lh + q;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(xl + hp * XPIX_BYTES + (i0 + 4 * p) * 2));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (__attribute__((address_space(3))) s16x4*)(xl + (hp + 4) * XPIX_BYTES + (i0 + 4 * p) * 2));
-                        const bf16x8 bf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                        for (int t2 = 0; t2 < NT; ++t2)
-                            acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t2], bf, acc[kx][t2], 0, 0, 0);
+                        const uint4 u = __builtin_bit_cast(uint4, fa[cur][t2]);
+                        float sacc = bsum[t2];
+                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.x), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.y), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.z), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.w), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        bsum[t2] = sacc;
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch one step ahead, not further (VGPR budget)
             }
+#undef TR_WG_FRAGS
+#undef TR_TRRD
         } else {
             for (int r = r_first; r < TH; r += r_step) {
 #pragma unroll 4
@@ -301,6 +314,10 @@ Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3) {
     int target = 768 / (p.nchunks * p.ncg);      // ~3 workgroups of 3 waves per CU
     if (target < 1) target = 1;
     p.nslots = p.ntiles < target ? p.ntiles : target;
+    // workgroup id = slot + nslots * (chunk + nchunks * cg) and ids are dealt round-robin to the 8 XCDs: with nslots a multiple of 8
+    // the (chunk, cg) workgroups that walk the SAME tiles sit on one XCD and share its L2 instead of each pulling the tile from HBM
+    static const bool xcd_align = !(getenv("TRAINNER_WGRAD_XCD") && atoi(getenv("TRAINNER_WGRAD_XCD")) == 0);   // A/B switch
+    if (xcd_align && p.nslots >= 8) p.nslots &= ~7;
     const int mult = ks == 1 ? 3 : 1;
     p.dw_floats = (size_t)p.nslots * mult * p.nchunks * p.ncg * p.cgw * ks * ks * CKW;
     p.db_floats = (size_t)p.nslots * mult * p.ncg * p.cgw;
