@@ -34,8 +34,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s"],
-                    help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles)")
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s", "span", "span_s"],
+                    help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles); "
+                         "span* = configs[4] (2x, batch 64 per GPU; bf16 here, the fp16 + GradScaler path is not built)")
+    ap.add_argument("--scale", type=int, default=None, help="default 4 (2 for span)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan = configs[1], 8 for swinir = configs[3] / SURVEY.md cfg4)")
     ap.add_argument("--lq", type=int, default=None, help="LR tile size (default 256 for esrgan, 64 for swinir)")
     ap.add_argument("--blocks", type=int, default=23)
@@ -45,7 +47,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     swin = args.arch != "esrgan"
-    args.batch = args.batch or (8 if swin else 16)
+    span = args.arch.startswith("span")
+    args.scale = args.scale or (2 if span else 4)
+    args.batch = args.batch or (64 if span else 8 if swin else 16)
     args.lq = args.lq or (64 if swin else 256)
     if swin and args.losses != "l1":
         args.losses = "l1"            # configs[3] names no perceptual head; the reference's SwinIR template trains on a pixel loss
@@ -61,8 +65,8 @@ def make_opt(args):
     elif args.losses == "l1+perceptualfp16":
         losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
     return parse_options_dict(dict(
-        name="bench", scale=4, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute == "bf16", amp_bf16=True,
-        network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=4),
+        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute == "bf16", amp_bf16=True,
+        network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=args.scale),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
                    optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
@@ -137,6 +141,13 @@ def cpu_baseline(args, perceptual: bool):
         hp = OE.esrgan_hparams(scale=4, num_blocks=args.blocks)
         sd = OE.init_state_dict(hp, 0)
         fwd = lambda p, x: OE.forward(p, x, hp)  # noqa: E731
+    elif args.arch.startswith("span"):
+        from oracle import span as OSP
+
+        hp = OSP.hparams(feature_channels=52 if args.arch == "span" else 48, scale=args.scale)
+        g0 = torch.Generator().manual_seed(0)
+        sd = OrderedDict((k, torch.randn(shp, generator=g0) * 0.05) for k, shp in OSP.param_table(hp).items() if "eval_conv" not in k)
+        fwd = lambda p, x: OSP.forward(p, x, hp)  # noqa: E731
     else:
         hp = OW.hparams(args.arch, scale=4)
         sd = OW.init_state_dict(hp, 0)
@@ -146,8 +157,8 @@ def cpu_baseline(args, perceptual: bool):
     ema = OS.EMAState(OrderedDict((k, v.data) for k, v in params.items()), beta=0.999, power=0.75)
     g = torch.Generator().manual_seed(1024)
     s_lq = 64
-    gt = torch.rand(1, 3, 4 * s_lq, 4 * s_lq, generator=g)
-    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    gt = torch.rand(1, 3, args.scale * s_lq, args.scale * s_lq, generator=g)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=1.0 / args.scale, mode="bicubic", antialias=True).clamp(0, 1)
     fns = OrderedDict(l_g_l1=(OL.l1, 1.0))
     if perceptual:
         vsd = OV.synthetic_state_dict(0)
@@ -163,8 +174,8 @@ def cpu_baseline(args, perceptual: bool):
     dt = (time.perf_counter() - t0) / reps
     scale = (args.lq / s_lq) ** 2
     return dict(value=1.0 / (dt * scale), unit="images/sec", cores=threads, kind="port",
-                sample=f"{reps} oracle steps of batch 1 at {s_lq}->{4 * s_lq} ({dt:.2f} s each, fp32, {threads} threads); "
-                       f"one {args.lq}->{4 * args.lq} image = {scale:.0f}x those pixels, value scaled by 1/{scale:.0f}")
+                sample=f"{reps} oracle steps of batch 1 at {s_lq}->{args.scale * s_lq} ({dt:.2f} s each, fp32, {threads} threads); "
+                       f"one {args.lq}->{args.scale * args.lq} image = {scale:.0f}x those pixels, value scaled by 1/{scale:.0f}")
 
 
 def main():
@@ -193,8 +204,9 @@ def main():
         dist.broadcast(p, 0)
     torch.manual_seed(1024 + rank)
     n, s = args.batch, args.lq
-    gt = torch.rand(n, 3, 4 * s, 4 * s, device=dev)
-    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    sc = args.scale
+    gt = torch.rand(n, 3, sc * s, sc * s, device=dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=1.0 / sc, mode="bicubic", antialias=True).clamp(0, 1)
     batch = {"lq": lq, "gt": gt}
     timer = ConvTimer()
     if not args.no_roofline:
@@ -235,12 +247,12 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": f"training images/sec ({s}->{4 * s} 4x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SwinIR"),
+            "metric": f"training images/sec ({s}->{sc * s} {sc}x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SPAN" if args.arch.startswith("span") else "SwinIR"),
             "value": n * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"SwinIR 4x ({args.arch})")
-                                   + f" {args.losses} {args.compute}, {s}->{4 * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+            "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
+                                   + f" {args.losses} {args.compute}, {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }

@@ -36,9 +36,9 @@ extern "C" {
 
 enum { TR_F32 = 0, TR_BF16 = 1 };
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
-enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3 };
+enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3, TR_ACT_SILU = 4 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
-enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2 };
+enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2, TR_IN_VALID = 3 };
 enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
 enum { TR_GAN_VANILLA = 0, TR_GAN_LSGAN = 1, TR_GAN_WGAN = 2, TR_GAN_WGAN_SOFTPLUS = 3, TR_GAN_HINGE = 4 };
 
@@ -82,7 +82,9 @@ typedef struct tr_conv3x3_desc {
     int32_t compute;          /* TR_F32 | TR_BF16                                             */
     int32_t in_mode;          /* TR_IN_DIRECT (input n x h x w) | TR_IN_NEAREST2X (n x h/2 x w/2) |
                                  TR_IN_FULL (input n x (h-2) x (w-2): 'full' correlation, out(y,x) = sum in(y+ky-2, x+kx-2) W,
-                                 i.e. the input gradient of a conv over an explicitly padded image)              */
+                                 i.e. the input gradient of a conv over an explicitly padded image) |
+                                 TR_IN_VALID (input n x (h+2) x (w+2), no padding: out(y,x) = sum in(y+ky, x+kx) W for ksize 3,
+                                 in(y+1, x+1) for ksize 1 -- the padding-free 3x3 of SPAN's Conv3XC, span_arch.py:134-141,199-204) */
     int32_t pad_mode;         /* TR_PAD_ZEROS | TR_PAD_REPLICATE                              */
     int32_t act;              /* TR_ACT_*                                                     */
     float   slope;            /* LeakyReLU negative slope                                     */
@@ -95,9 +97,9 @@ typedef struct tr_conv3x3_desc {
     const float* bias;        /* cout floats or NULL                                          */
     int32_t ksize;            /* 3 (3x3, pad 1) or 1 (1x1: nn.Linear over tokens laid out as an n x h x w grid,
                                  traiNNer/archs/drct_arch.py:64-66,166-168)                     */
-    int32_t mask_mode;        /* 0: LeakyReLU/ReLU derivative by sign ; 1: exact-GELU derivative of `mask`   */
+    int32_t mask_mode;        /* 0: LeakyReLU/ReLU derivative by sign ; 1: exact-GELU derivative of `mask` ; 2: SiLU derivative */
     const float* sample_scale;/* optional n floats multiplied into v per image before res1 (DropPath keep mask,
-                                 drct_arch.py:572-573); with act = TR_ACT_GELU, out2 receives the pre-activation */
+                                 drct_arch.py:572-573); with act = TR_ACT_GELU / TR_ACT_SILU, out2 receives the pre-activation */
 } tr_conv3x3_desc;
 
 int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
@@ -148,7 +150,8 @@ typedef struct tr_wgrad3x3_desc {
     int32_t n, h, w;          /* spatial size of gy (= conv output size)                      */
     int32_t cin, cout;
     int32_t compute;
-    int32_t in_mode, pad_mode;
+    int32_t in_mode, pad_mode;  /* in_mode as in tr_conv3x3_desc: TR_IN_FULL reads in(y+ky-2, x+kx-2) of an (h-2) x (w-2) input (zero outside),
+                                   TR_IN_VALID reads in(y+ky, x+kx) of an (h+2) x (w+2) input; for ksize 1 the centre tap only */
     int32_t accumulate;
     tr_view in, gy;
     float*  dw;               /* cout x cin x 3 x 3                                           */
@@ -156,7 +159,9 @@ typedef struct tr_wgrad3x3_desc {
     float*  partials;
     size_t  partials_bytes;
     int32_t ksize;            /* 3 or 1 (dw is then cout x cin, the nn.Linear weight gradient) */
-    int32_t reserved;
+    int32_t dw_ld;            /* 0, or the input-channel count of the tensor `dw` points INTO when this launch fills the column block
+                                 [ci0, ci0 + cin) of a wider weight (dw = base + ci0 * ksize^2): torch.cat'ed inputs whose slices are
+                                 stored apart (span_arch.py:319-320) */
 } tr_wgrad3x3_desc;
 
 size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout);
@@ -312,6 +317,12 @@ typedef struct tr_adamw_desc {
     int32_t zero_grad;
 } tr_adamw_desc;
 int tr_adamw_ema(void* stream, const tr_adamw_desc* d);
+
+/* ---- SPAN parameter-free attention (span_arch.py:243-247): sim_att = sigmoid(o3) - 0.5 ; out = (o3 + x) * sim_att --------------
+ * forward writes out (any dtype) and optionally a second copy out2; backward, given g = d/d(out):
+ *   g_o3 = g * (sim_att + (o3 + x) * s * (1 - s)),  g_x = g * sim_att   (s = sigmoid(o3)); gx (+)= when accumulate_gx != 0. */
+int tr_span_gate(void* stream, tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix);
+int tr_span_gate_bwd(void* stream, tr_view g, tr_view o3, tr_view x, tr_view g_o3, tr_view g_x, int accumulate_gx, int64_t npix);
 
 #ifdef __cplusplus
 }

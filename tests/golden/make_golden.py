@@ -12,6 +12,9 @@ Fixtures
   sampler.pt            data_sampler.EnlargedSampler index streams (epoch-seeded permutation, rank stride)
   unet_discriminator_sn.pt  discriminator_arch.UNetDiscriminatorSN(num_feat=16): weights/u/v before and after one training-mode
                         forward, output, input- and parameter-gradients, eval-mode output
+  span.pt               span_arch.SPAN (feature_channels 8 / x2 / no norm, and 12 / x4 / norm): state dict, training-mode output (the
+                        1x1 -> 3x3 -> 1x1 + skip form of Conv3XC), parameter gradients for a fixed cotangent, eval-mode output (merged
+                        3x3) and the merged eval_conv weights.  `spandrel.util.store_hyperparameters` (absent wheel) is a no-op decorator here.
 """
 import importlib.util
 import os
@@ -130,6 +133,42 @@ def main():
     with torch.no_grad():
         fix["y_eval"] = net(x.detach())
     torch.save(fix, os.path.join(OUT, "unet_discriminator_sn.pt"))
+
+    # ---- SPAN (span_arch.py is torch-only apart from spandrel's hyper-parameter recorder)
+    _stub("spandrel")
+    su = _stub("spandrel.util")
+    su.store_hyperparameters = lambda *a, **k: (lambda cls: cls)
+    sp = _load("traiNNer.archs.span_arch", "traiNNer/archs/span_arch.py") if "traiNNer.archs" in sys.modules else None
+    if sp is None:
+        _stub("traiNNer.archs")
+        sp = _load("traiNNer.archs.span_arch", "traiNNer/archs/span_arch.py")
+    fix = {}
+    for tag, kw, shape in (("fc8_x2", dict(feature_channels=8, upscale=2, norm=False), (2, 3, 12, 10)),
+                           ("fc12_x4_norm", dict(feature_channels=12, upscale=4, norm=True, img_range=255.0), (1, 3, 9, 16))):
+        torch.manual_seed(7)
+        net = sp.SPAN(num_in_ch=3, num_out_ch=3, **kw).train()
+        # default init leaves every bias at nn.Conv2d's small uniform value; widen them so the bias-at-the-padded-border effect shows
+        with torch.no_grad():
+            for k, p_ in net.named_parameters():
+                if k.endswith("bias"):
+                    p_.mul_(4.0)
+            for m in net.modules():
+                if isinstance(m, sp.Conv3XC):
+                    m.update_params()
+        g = torch.Generator().manual_seed(11)
+        x = torch.rand(*shape, generator=g)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        y = net(x)
+        gy = torch.randn(y.shape, generator=g) / y.numel()
+        y.backward(gy)
+        e = {"kwargs": kw, "x": x, "gy": gy, "state": sd0, "y_train": y.detach().clone(),
+             "grads": {k: p_.grad.clone() for k, p_ in net.named_parameters() if p_.grad is not None}}
+        net.eval()
+        with torch.no_grad():
+            e["y_eval"] = net(x)
+        e["state_eval"] = {k: v.clone() for k, v in net.state_dict().items() if "eval_conv" in k}
+        fix[tag] = e
+    torch.save(fix, os.path.join(OUT, "span.pt"))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".pt")))
 
 

@@ -14,6 +14,10 @@ import torch
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
 def test_esrgan_param_count_checksums():
     from oracle import esrgan as OE
 
@@ -141,3 +145,35 @@ def test_discriminator_oracle_matches_reference_golden():
     with torch.no_grad():
         ye, _ = OD.forward(sd_after, fix["x"], training=False)
     assert torch.allclose(ye, fix["y_eval"], rtol=1e-5, atol=1e-6)
+
+
+def test_span_oracle_matches_reference_module_goldens():
+    """oracle/span.py against the reference's OWN SPAN module (tests/golden/span.pt, made by make_golden.py from span_arch.py):
+    training-mode output (Conv3XC's 1x1 -> 3x3 -> 1x1 + skip form), every parameter gradient, eval-mode output (merged 3x3), merged weights."""
+    import os
+    from collections import OrderedDict
+
+    from oracle import span as OS
+
+    fix = torch.load(os.path.join(os.path.dirname(__file__), "golden", "span.pt"), weights_only=True)
+    for tag, e in fix.items():
+        kw = e["kwargs"]
+        hp = OS.hparams(feature_channels=kw["feature_channels"], scale=kw["upscale"], norm=kw["norm"], img_range=kw.get("img_range", 255.0))
+        sd = e["state"]
+        assert [k for k in OS.param_table(hp)] == [k for k in sd if k != "no_norm"], tag
+        assert all(tuple(sd[k].shape) == shp for k, shp in OS.param_table(hp).items())
+        params = OrderedDict((k, v.clone().requires_grad_(v.dtype.is_floating_point and "eval_conv" not in k)) for k, v in sd.items())
+        y = OS.forward(params, e["x"], hp, train=True)
+        assert rel_l2(y, e["y_train"]) < 2e-6, (tag, rel_l2(y, e["y_train"]))
+        names = list(e["grads"].keys())
+        grads = torch.autograd.grad(y, [params[k] for k in names], e["gy"])
+        worst = max(rel_l2(g, e["grads"][k]) for k, g in zip(names, grads))
+        assert worst < 2e-5, (tag, worst)
+        with torch.no_grad():
+            ye = OS.forward(sd, e["x"], hp, train=False)
+            assert rel_l2(ye, e["y_eval"]) < 2e-6
+            # training and eval forms are the same function (the merged kernel reproduces the bias seen at the padded border)
+            assert rel_l2(ye, e["y_train"]) < 1e-5
+            for name in OS.conv3xc_names(hp):
+                w, b = OS.merged_kernel(sd, name)
+                assert rel_l2(w, e["state_eval"][name + ".eval_conv.weight"]) < 1e-6 and rel_l2(b, e["state_eval"][name + ".eval_conv.bias"]) < 1e-6

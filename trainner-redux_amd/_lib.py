@@ -13,9 +13,9 @@ LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 PAD_ZEROS, PAD_REPLICATE = 0, 1
-IN_DIRECT, IN_NEAREST2X, IN_FULL = 0, 1, 2
+IN_DIRECT, IN_NEAREST2X, IN_FULL, IN_VALID = 0, 1, 2, 3
 LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
 GAN_TYPES = {"vanilla": 0, "lsgan": 1, "wgan": 2, "wgan_softplus": 3, "hinge": 4}
 
@@ -56,7 +56,7 @@ class Wgrad3x3Desc(C.Structure):
         ("compute", C.c_int32), ("in_mode", C.c_int32), ("pad_mode", C.c_int32), ("accumulate", C.c_int32),
         ("inp", View), ("gy", View),
         ("dw", C.c_void_p), ("db", C.c_void_p), ("partials", C.c_void_p), ("partials_bytes", C.c_size_t),
-        ("ksize", C.c_int32), ("reserved", C.c_int32),
+        ("ksize", C.c_int32), ("dw_ld", C.c_int32),
     ]
 
 
@@ -124,6 +124,8 @@ SYMBOLS = {
     "tr_window_attention_bwd": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),
     "tr_pixel_shuffle": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64, View, C.c_float, C.c_void_p, C.c_int64]),
+    "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
+    "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
     "tr_depth_to_space2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
     "tr_expand_w4x4s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

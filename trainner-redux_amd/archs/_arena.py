@@ -76,3 +76,24 @@ class FlatParamModule(nn.Module):
         """(params arena, grads arena) -- consumed by the fused AdamW/EMA sweep and the gradient all-reduce."""
         self._ensure_arena()
         return self._arena, self._grad_arena
+
+    def _pool(self, phase: str, dev, cdt):
+        """Activation / gradient buffers are drawn in a fixed order every step, so the n-th request of a phase reuses the n-th
+        buffer of the previous step (no allocator traffic, no per-step memset).  Saved activations therefore belong to the LATEST
+        training forward: run its backward before the next forward of this module."""
+        pool = self._ws.setdefault(phase, [])
+        idx = [0]
+
+        def take(*shape, dt=cdt):
+            i = idx[0]
+            idx[0] += 1
+            if i < len(pool):
+                t = pool[i]
+                if t.shape == tuple(shape) and t.dtype == dt and t.device == dev:
+                    return t
+                del pool[i:]                        # geometry changed (another tile size / batch): rebuild from here on
+            t = torch.zeros(*shape, dtype=dt, device=dev)
+            pool.append(t)
+            return t
+
+        return take

@@ -227,28 +227,6 @@ class SwinIR(FlatParamModule):
             st["plan"] = plan.finalize()
         st["plan"].run()
 
-    # ------------------------------------------------------------------ buffers ------------------------------------------------
-    def _pool(self, phase: str, dev, cdt):
-        """Activation / gradient buffers are drawn in a fixed order every step, so the n-th request of a phase reuses the n-th
-        buffer of the previous step (no allocator traffic, no per-step memset).  Saved activations therefore belong to the LATEST
-        training forward: run its backward before the next forward of this module."""
-        pool = self._ws.setdefault(phase, [])
-        idx = [0]
-
-        def take(*shape, dt=cdt):
-            i = idx[0]
-            idx[0] += 1
-            if i < len(pool):
-                t = pool[i]
-                if t.shape == tuple(shape) and t.dtype == dt and t.device == dev:
-                    return t
-                del pool[i:]                        # geometry changed (another tile size / batch): rebuild from here on
-            t = torch.zeros(*shape, dtype=dt, device=dev)
-            pool.append(t)
-            return t
-
-        return take
-
     # ------------------------------------------------------------------ forward ------------------------------------------------
     def _keep_masks(self, b, dev):
         """DropPath (drct_arch.py:572-573): per block and sample, keep/(1-p) with p rising linearly over the blocks."""

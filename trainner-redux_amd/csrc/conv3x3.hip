@@ -99,6 +99,10 @@ __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, 
     }
 }
 
+__device__ __forceinline__ float silu_grad(float x) {   // d/dx [x * sigmoid(x)]
+    const float sg = 1.f / (1.f + __expf(-x));
+    return sg * (1.f + x * (1.f - sg));
+}
 __device__ __forceinline__ float gelu_grad(float x) {   // d/dx [x * Phi(x)], exact (erf) GELU like nn.GELU()
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
     return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
@@ -159,10 +163,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
             }
-            float pre[4] = {v[0], v[1], v[2], v[3]};   // value before GELU: what out2 stores in GELU mode (needed by the backward)
+            float pre[4] = {v[0], v[1], v[2], v[3]};   // value before GELU / SiLU: what out2 stores in those modes (needed by the backward)
             if (a.act == TR_ACT_GELU) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+            } else if (a.act == TR_ACT_SILU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.f + __expf(-v[k]));
             }
             if (a.sample_scale) {
                 const float ss = a.sample_scale[nb];
@@ -184,6 +191,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                     const float4 mm = tr::view_load4(a.mask, pix, co, true);
                     if (a.mask_mode == 1) {
                         v[0] *= gelu_grad(mm.x); v[1] *= gelu_grad(mm.y); v[2] *= gelu_grad(mm.z); v[3] *= gelu_grad(mm.w);
+                    } else if (a.mask_mode == 2) {
+                        v[0] *= silu_grad(mm.x); v[1] *= silu_grad(mm.y); v[2] *= silu_grad(mm.z); v[3] *= silu_grad(mm.w);
                     } else {
                         v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
                         v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
@@ -192,7 +201,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                 tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), true);
                 if (a.out2.ptr) {
                     const float sc = a.out2_scale;
-                    if (a.act == TR_ACT_GELU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
+                    if (a.act == TR_ACT_GELU || a.act == TR_ACT_SILU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
                     else tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
                 }
             } else {
@@ -202,10 +211,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                     if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
                     if (a.mask.ptr) {
                         const float m = tr::view_load(a.mask, pix, co + k);
-                        x *= a.mask_mode == 1 ? gelu_grad(m) : (m > 0.f ? 1.f : a.mask_slope);
+                        x *= a.mask_mode == 1 ? gelu_grad(m) : a.mask_mode == 2 ? silu_grad(m) : (m > 0.f ? 1.f : a.mask_slope);
                     }
                     tr::view_store(a.out, pix, co + k, x);
-                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, a.act == TR_ACT_GELU ? pre[k] : x * a.out2_scale);
+                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, (a.act == TR_ACT_GELU || a.act == TR_ACT_SILU) ? pre[k] : x * a.out2_scale);
                 }
             }
         }
@@ -629,12 +638,14 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
                "tr_conv3x3: nearest-2x input needs even output dims");
     TR_REQUIRE(d->in_mode != TR_IN_FULL || (d->h > 2 && d->w > 2 && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL,
                "tr_conv3x3: full mode needs output dims > 2 and zero padding");
+    TR_REQUIRE(d->in_mode != TR_IN_VALID || d->pad_mode == TR_PAD_ZEROS, TR_EINVAL, "tr_conv3x3: valid mode has no padding to replicate");
+    TR_REQUIRE(d->in_mode >= TR_IN_DIRECT && d->in_mode <= TR_IN_VALID, TR_EINVAL, "tr_conv3x3: bad in_mode %d", d->in_mode);
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3: wpacked must be 16-byte aligned");
 
     ConvArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w;
     a.up = d->in_mode == TR_IN_NEAREST2X ? 1 : 0;
-    a.shift = d->in_mode == TR_IN_FULL ? 1 : 0;
+    a.shift = d->in_mode == TR_IN_FULL ? 1 : (d->in_mode == TR_IN_VALID ? -1 : 0);   // input origin relative to the output origin
     a.ih = d->h - 2 * a.shift; a.iw = d->w - 2 * a.shift;
     a.hin = a.ih >> a.up; a.win = a.iw >> a.up;
     a.cin = d->cin; a.cout = d->cout;
@@ -660,8 +671,8 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     static const int force_r = getenv("TRAINNER_CONV_R") ? atoi(getenv("TRAINNER_CONV_R")) : 0;
     const bool roomy = d->h >= 16 && (int64_t)d->n * ((d->h + 15) / 16) * a.ntx * g.ncg >= 512;
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_conv3x3: ksize must be 3 or 1 (got %d)", d->ksize);
-    TR_REQUIRE(d->ksize == 3 || (d->in_mode == TR_IN_DIRECT && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct input");
-    if (use_dma && d->ksize == 3) {
+    TR_REQUIRE(d->ksize == 3 || (d->in_mode != TR_IN_NEAREST2X && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct / full / valid input");
+    if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID) {
         TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
                    "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
         const bool big = force_r ? force_r == 4 : roomy;
@@ -678,7 +689,7 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     const bool big = g.cgw == 32 && (force_r ? force_r == 4 : roomy);
     const bool bf = d->compute == TR_BF16;
     static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
-    if (d->ksize == 1 && d->w == 32 && g.cgw == 64 && !no_linear) {
+    if (d->ksize == 1 && d->w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
         // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
         const int ncgb = g.ncg == 4 ? 2 : (g.ncg < 3 ? g.ncg : 3);
         const int nblk = (g.ncg + ncgb - 1) / ncgb;

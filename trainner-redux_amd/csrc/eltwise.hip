@@ -64,6 +64,50 @@ __global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view
     }
 }
 
+
+// ---- SPAN parameter-free attention (span_arch.py:243-247) ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void span_gate_kernel(tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix, int c4, int v3, int vx, int vo,
+                                                         int vo2) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int c = (int)(i - p * c4) * 4;
+        const float4 a = tr::view_load4(o3, p, c, v3), b = tr::view_load4(x, p, c, vx);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (av[k] + bv[k]) * (1.f / (1.f + __expf(-av[k])) - 0.5f);
+        const float4 o = make_float4(r[0], r[1], r[2], r[3]);
+        tr::view_store4(out, p, c, o, vo);
+        if (out2.ptr) tr::view_store4(out2, p, c, o, vo2);
+    }
+}
+__global__ __launch_bounds__(256) void span_gate_bwd_kernel(tr_view g, tr_view o3, tr_view x, tr_view g3, tr_view gx, int acc, int64_t npix, int c4, int vg,
+                                                             int v3, int vx, int vg3, int vgx) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int c = (int)(i - p * c4) * 4;
+        const float4 gg = tr::view_load4(g, p, c, vg), a = tr::view_load4(o3, p, c, v3), b = tr::view_load4(x, p, c, vx);
+        const float gv[4] = {gg.x, gg.y, gg.z, gg.w}, av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        float r3[4], rx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = 1.f / (1.f + __expf(-av[k]));
+            rx[k] = gv[k] * (sg - 0.5f);
+            r3[k] = rx[k] + gv[k] * (av[k] + bv[k]) * sg * (1.f - sg);
+        }
+        tr::view_store4(g3, p, c, make_float4(r3[0], r3[1], r3[2], r3[3]), vg3);
+        if (gx.ptr) {
+            if (acc) {
+                const float4 o = tr::view_load4(gx, p, c, vgx);
+                rx[0] += o.x; rx[1] += o.y; rx[2] += o.z; rx[3] += o.w;
+            }
+            tr::view_store4(gx, p, c, make_float4(rx[0], rx[1], rx[2], rx[3]), vgx);
+        }
+    }
+}
+
 // one thread = one LOW-resolution pixel x 4 channels
 __global__ __launch_bounds__(256) void sumpool_kernel(tr_view in, tr_view out, tr_view mask, float mslope, int n, int hin, int win, int vin,
                                                        int vout, int vmask) {
@@ -202,6 +246,22 @@ extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, 
                        (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out), mask, mask_slope, (int)tr::view_vec4_ok(mask),
                        sample_scale, pix_per_sample > 0 ? pix_per_sample : npix);
     return tr::launch_status("tr_axpby");
+}
+
+extern "C" int tr_span_gate(void* stream, tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix) {
+    TR_REQUIRE(o3.ptr && x.ptr && out.ptr && npix > 0 && o3.c % 4 == 0 && x.c == o3.c && out.c == o3.c && (!out2.ptr || out2.c == o3.c), TR_EINVAL,
+               "tr_span_gate: views must have equal channel counts that are multiples of 4");
+    hipLaunchKernelGGL(span_gate_kernel, dim3(grid_for(npix * (o3.c / 4))), dim3(256), 0, (hipStream_t)stream, o3, x, out, out2, npix, o3.c / 4,
+                       (int)tr::view_vec4_ok(o3), (int)tr::view_vec4_ok(x), (int)tr::view_vec4_ok(out), (int)tr::view_vec4_ok(out2));
+    return tr::launch_status("tr_span_gate");
+}
+extern "C" int tr_span_gate_bwd(void* stream, tr_view g, tr_view o3, tr_view x, tr_view g_o3, tr_view g_x, int accumulate_gx, int64_t npix) {
+    TR_REQUIRE(g.ptr && o3.ptr && x.ptr && g_o3.ptr && npix > 0 && o3.c % 4 == 0 && g.c == o3.c && x.c == o3.c && g_o3.c == o3.c &&
+                   (!g_x.ptr || g_x.c == o3.c), TR_EINVAL, "tr_span_gate_bwd: views must have equal channel counts that are multiples of 4");
+    hipLaunchKernelGGL(span_gate_bwd_kernel, dim3(grid_for(npix * (o3.c / 4))), dim3(256), 0, (hipStream_t)stream, g, o3, x, g_o3, g_x, accumulate_gx, npix,
+                       o3.c / 4, (int)tr::view_vec4_ok(g), (int)tr::view_vec4_ok(o3), (int)tr::view_vec4_ok(x), (int)tr::view_vec4_ok(g_o3),
+                       (int)tr::view_vec4_ok(g_x));
+    return tr::launch_status("tr_span_gate_bwd");
 }
 
 extern "C" int tr_sumpool2x2(void* stream, tr_view in, tr_view out, tr_view mask, float mask_slope, int n, int h_in, int w_in) {

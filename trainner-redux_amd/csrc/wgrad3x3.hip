@@ -30,6 +30,7 @@ constexpr int CKW = 32;   // input channels per workgroup
 
 struct WgArgs {
     int n, h, w, hin, win;
+    int ih, iw, shift;   // input extent in output coordinates and its origin shift (TR_IN_FULL: +1, TR_IN_VALID: -1)
     int cin, cout;
     int up, replicate;
     tr_view in, gy;
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
             const int it = tb + j * NTHREADS;                                                                            \
             const int pp = it / XSLOTS, s_ = it - pp * XSLOTS;                                                           \
             const int py = pp / HALO_W, px = pp - py * HALO_W;                                                           \
-            int oy = y0_ + py - PAD, ox = x0_ + px - PAD;                                                                    \
-            bool ok = (it < X_ITEMS) & (oy >= 0) & (oy < a.h) & (ox >= 0) & (ox < a.w);                                  \
+            int oy = y0_ + py - PAD - a.shift, ox = x0_ + px - PAD - a.shift;                                                \
+            bool ok = (it < X_ITEMS) & (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);                                \
             if (a.replicate) {                                                                                          \
-                oy = min(max(oy, 0), a.h - 1);                                                                           \
-                ox = min(max(ox, 0), a.w - 1);                                                                           \
+                oy = min(max(oy, 0), a.ih - 1);                                                                          \
+                ox = min(max(ox, 0), a.iw - 1);                                                                          \
                 ok = it < X_ITEMS;                                                                                       \
             }                                                                                                           \
             const int c0 = chunk * CKW + s_ * EPS;                                                                       \
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
 // (per-slot column sums written by the (chunk 0, ky 0) waves) -- one launch for both
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
                                                             int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
-                                                            const float* __restrict__ db_partials, float* __restrict__ db) {
+                                                            const float* __restrict__ db_partials, float* __restrict__ db, int ld) {
     if ((int)blockIdx.x >= nb_dw) {
         const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
         if (co >= cout) return;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         for (; k < nslots; ++k) s0 += p[k * stride];
         const float s = (s0 + s1) + (s2 + s3);
-        float* o = dw + ((int64_t)co * cin + ci) * taps + tap;
+        float* o = dw + ((int64_t)co * ld + ci) * taps + tap;
         *o = accumulate ? *o + s : s;
     }
 }
@@ -362,8 +363,12 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
                "tr_wgrad3x3: view channel counts must be multiples of %d covering cin/cout", eps);
     TR_REQUIRE(tr::view_vec16B_ok(d->in) && tr::view_vec16B_ok(d->gy), TR_EALIGN, "tr_wgrad3x3: views are not 16-byte sliceable");
     TR_REQUIRE(d->in.coff + d->in.c <= d->in.cstride && d->gy.coff + d->gy.c <= d->gy.cstride, TR_EINVAL, "tr_wgrad3x3: view exceeds its buffer");
-    TR_REQUIRE(d->in_mode == TR_IN_DIRECT || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL, "tr_wgrad3x3: nearest-2x input needs even dims");
+    TR_REQUIRE(d->in_mode != TR_IN_NEAREST2X || (d->h % 2 == 0 && d->w % 2 == 0), TR_EINVAL, "tr_wgrad3x3: nearest-2x input needs even dims");
+    TR_REQUIRE(d->in_mode >= TR_IN_DIRECT && d->in_mode <= TR_IN_VALID && (d->in_mode != TR_IN_FULL || (d->h > 2 && d->w > 2)), TR_EINVAL,
+               "tr_wgrad3x3: bad in_mode");
+    TR_REQUIRE(d->in_mode < TR_IN_FULL || d->pad_mode == TR_PAD_ZEROS, TR_EINVAL, "tr_wgrad3x3: full / valid modes take zero padding");
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_wgrad3x3: ksize must be 3 or 1");
+    TR_REQUIRE(d->dw_ld == 0 || d->dw_ld >= d->cin, TR_EINVAL, "tr_wgrad3x3: dw_ld must be 0 or >= cin");
     const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout, d->ksize);
     TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
                "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
@@ -371,7 +376,9 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     WgArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w;
     a.up = d->in_mode == TR_IN_NEAREST2X ? 1 : 0;
-    a.hin = d->h >> a.up; a.win = d->w >> a.up;
+    a.shift = d->in_mode == TR_IN_FULL ? 1 : (d->in_mode == TR_IN_VALID ? -1 : 0);
+    a.ih = d->h - 2 * a.shift; a.iw = d->w - 2 * a.shift;
+    a.hin = a.ih >> a.up; a.win = a.iw >> a.up;
     a.cin = d->cin; a.cout = d->cout;
     a.replicate = d->pad_mode == TR_PAD_REPLICATE;
     a.in = d->in; a.gy = d->gy;
@@ -396,7 +403,7 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
         if (b > 2048) b = 2048;
         const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult,
-                           p.nchunks, p.ncg, p.cgw, d->accumulate, taps, (int)b, d->partials + p.dw_floats, d->db);
+                           p.nchunks, p.ncg, p.cgw, d->accumulate, taps, (int)b, d->partials + p.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
         rc = tr::launch_status("tr_wgrad3x3(reduce)");
     }
     return rc;

@@ -120,14 +120,16 @@ def wgrad_workspace_bytes(n, h, w, cin, cout, ksize: int = 3) -> int:
 
 
 def wgrad3x3(*, n, h, w, cin, cout, compute, inp: L.View, gy: L.View, dw: torch.Tensor, db: torch.Tensor | None, workspace: torch.Tensor,
-             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, accumulate=False, ksize=3):
+             in_mode=L.IN_DIRECT, pad_mode=L.PAD_ZEROS, accumulate=False, ksize=3, dw_ci0=0, dw_ld=0):
+    """dw_ld / dw_ci0: fill the input-channel block [dw_ci0, dw_ci0 + cin) of a weight whose full input width is dw_ld."""
     d = L.Wgrad3x3Desc()
     d.n, d.h, d.w, d.cin, d.cout = n, h, w, cin, cout
     d.compute, d.in_mode, d.pad_mode, d.accumulate = compute, in_mode, pad_mode, 1 if accumulate else 0
     d.inp, d.gy = inp, gy
     d.ksize = ksize
-    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * cin * ksize * ksize
-    d.dw = dw.data_ptr()
+    d.dw_ld = dw_ld
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == cout * (dw_ld or cin) * ksize * ksize and dw_ci0 + cin <= (dw_ld or cin)
+    d.dw = dw.data_ptr() + 4 * dw_ci0 * ksize * ksize
     d.db = db.data_ptr() if db is not None else None
     d.partials = workspace.data_ptr()
     d.partials_bytes = workspace.numel() * workspace.element_size()
@@ -236,6 +238,15 @@ def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, ma
           sample_scale: torch.Tensor | None = None, pix_per_sample: int = 0):
     L.check(L.lib().tr_axpby(stream_ptr(), a, sa, b, sb, out, npix, mask if mask is not None else NULL_VIEW, mask_slope,
                              sample_scale.data_ptr() if sample_scale is not None else None, pix_per_sample), "tr_axpby")
+
+
+def span_gate(o3: L.View, x: L.View, out: L.View, out2: L.View | None, npix: int):
+    L.check(L.lib().tr_span_gate(stream_ptr(), o3, x, out, out2 if out2 is not None else NULL_VIEW, npix), "tr_span_gate")
+
+
+def span_gate_bwd(g: L.View, o3: L.View, x: L.View, g_o3: L.View, g_x: L.View | None, npix: int, accumulate_gx: bool = False):
+    L.check(L.lib().tr_span_gate_bwd(stream_ptr(), g, o3, x, g_o3, g_x if g_x is not None else NULL_VIEW, 1 if accumulate_gx else 0, npix),
+            "tr_span_gate_bwd")
 
 
 def space_to_depth2(inp: L.View, out: L.View, n, h, w):
