@@ -495,7 +495,10 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
         hipFuncSetAttribute((const void*)conv3x3_kernel_reg<CT, NT, R, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    static const int persist = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 512;   // 2 per CU
+    // resident workgroups: 2 per CU, or 3 for the 8-row / 32-channel tile (164 VGPRs, 40 KB LDS) -- measured +15 % on the thin
+    // RDB convs (cin <= 96), whose K loop is too short to hide the load latency with two workgroups
+    static const int persist_env = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 0;
+    const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && CT == TR_BF16) ? 768 : 512);
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
     const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
     hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R, KS>), dim3(grid), dim3(NTHREADS), lds, st, a);
@@ -644,9 +647,15 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
 
     ConvArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w;
+    if (d->ksize == 1 && d->in_mode == TR_IN_DIRECT && d->w != 32 && ((int64_t)d->h * d->w) % 32 == 0) {
+        // a direct 1x1 conv does not care how the pixels of an image are folded into rows: relabel them as a 32-wide token grid so
+        // that the GEMM-tiled kernel applies (rows of an image stay inside the image: per-sample scales still index by n)
+        a.h = (int)((int64_t)d->h * d->w / 32);
+        a.w = 32;
+    }
     a.up = d->in_mode == TR_IN_NEAREST2X ? 1 : 0;
     a.shift = d->in_mode == TR_IN_FULL ? 1 : (d->in_mode == TR_IN_VALID ? -1 : 0);   // input origin relative to the output origin
-    a.ih = d->h - 2 * a.shift; a.iw = d->w - 2 * a.shift;
+    a.ih = a.h - 2 * a.shift; a.iw = a.w - 2 * a.shift;
     a.hin = a.ih >> a.up; a.win = a.iw >> a.up;
     a.cin = d->cin; a.cout = d->cout;
     a.replicate = d->pad_mode == TR_PAD_REPLICATE;
@@ -663,20 +672,20 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     hipStream_t st = (hipStream_t)stream;
     static const int dbg = getenv("TRAINNER_CONV_DBG") ? atoi(getenv("TRAINNER_CONV_DBG")) : 0;
     a.dbg = dbg;
-    a.ntx = (d->w + TW - 1) / TW;
+    a.ntx = (a.w + TW - 1) / TW;
     // Staging variant and tile height.  Measured on MI355X (profiles/): the register-staged kernel at two workgroups per
     // CU beats the LDS-DMA kernel at one (each LDS-DMA piece costs the issuing wave 60-100 cycles and the per-CU DMA rate
     // does not cover a 76 KB stage inside one chunk of MFMAs), so it is the default; TRAINNER_CONV_STAGING=dma selects B.
     static const bool use_dma = getenv("TRAINNER_CONV_STAGING") && !strcmp(getenv("TRAINNER_CONV_STAGING"), "dma");
     static const int force_r = getenv("TRAINNER_CONV_R") ? atoi(getenv("TRAINNER_CONV_R")) : 0;
-    const bool roomy = d->h >= 16 && (int64_t)d->n * ((d->h + 15) / 16) * a.ntx * g.ncg >= 512;
+    const bool roomy = a.h >= 16 && (int64_t)d->n * ((a.h + 15) / 16) * a.ntx * g.ncg >= 512;
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_conv3x3: ksize must be 3 or 1 (got %d)", d->ksize);
     TR_REQUIRE(d->ksize == 3 || (d->in_mode != TR_IN_NEAREST2X && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct / full / valid input");
     if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID) {
         TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
                    "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
         const bool big = force_r ? force_r == 4 : roomy;
-        a.nty = big ? (d->h + 15) / 16 : (d->h + 7) / 8;
+        a.nty = big ? (a.h + 15) / 16 : (a.h + 7) / 8;
         if (big) {
             if (d->compute == TR_BF16) return g.cgw == 64 ? launch_dma<TR_BF16, 2, 4>(st, a, g.ncg) : launch_dma<TR_BF16, 1, 4>(st, a, g.ncg);
             return g.cgw == 64 ? launch_dma<TR_F32, 2, 4>(st, a, g.ncg) : launch_dma<TR_F32, 1, 4>(st, a, g.ncg);
@@ -686,32 +695,32 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     }
     // register-staged: 32-wide output groups take 16-row tiles (twice the MFMAs per staged weight slab); 64-wide groups
     // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
-    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : roomy);
+    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : (roomy && !(d->compute == TR_BF16 && d->ksize == 3 && d->cin <= 96)));
     const bool bf = d->compute == TR_BF16;
     static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
-    if (d->ksize == 1 && d->w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
+    if (d->ksize == 1 && a.w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
         // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
         const int ncgb = g.ncg == 4 ? 2 : (g.ncg < 3 ? g.ncg : 3);
         const int nblk = (g.ncg + ncgb - 1) / ncgb;
-        a.nty = (d->h + 3) / 4;
+        a.nty = (a.h + 3) / 4;
         if (ncgb == 3) return bf ? launch_linear<TR_BF16, 3>(st, a, nblk) : launch_linear<TR_F32, 3>(st, a, nblk);
         if (ncgb == 2) return bf ? launch_linear<TR_BF16, 2>(st, a, nblk) : launch_linear<TR_F32, 2>(st, a, nblk);
         return bf ? launch_linear<TR_BF16, 1>(st, a, nblk) : launch_linear<TR_F32, 1>(st, a, nblk);
     }
     if (d->ksize == 1) {
         if (big) {
-            a.nty = (d->h + 15) / 16;
+            a.nty = (a.h + 15) / 16;
             return bf ? launch_reg<TR_BF16, 1, 4, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 1>(st, a, g.ncg);
         }
-        a.nty = (d->h + 7) / 8;
+        a.nty = (a.h + 7) / 8;
         if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 1>(st, a, g.ncg);
         return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 1>(st, a, g.ncg);
     }
     if (big) {
-        a.nty = (d->h + 15) / 16;
+        a.nty = (a.h + 15) / 16;
         return bf ? launch_reg<TR_BF16, 1, 4, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 3>(st, a, g.ncg);
     }
-    a.nty = (d->h + 7) / 8;
+    a.nty = (a.h + 7) / 8;
     if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 3>(st, a, g.ncg);
     return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 3>(st, a, g.ncg);
 }
