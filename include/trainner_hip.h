@@ -324,6 +324,10 @@ int tr_adamw_ema(void* stream, const tr_adamw_desc* d);
 int tr_span_gate(void* stream, tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix);
 int tr_span_gate_bwd(void* stream, tr_view g, tr_view o3, tr_view x, tr_view g_o3, tr_view g_x, int accumulate_gx, int64_t npix);
 
+/* ---- feed: uint8 HWC image batch (what a decoder produces; 4x fewer PCIe bytes than the reference's fp32 CHW DataFeed,
+ * paired_image_dataset.py:133-146) -> fp32 NCHW in [0,1], optionally (x/255 - mean[c]) / std[c] (torchvision normalize, :141-143) */
+int tr_u8hwc_to_nchw(void* stream, const uint8_t* src, int n, int h, int w, int c, float* dst, const float* mean3, const float* std3);
+
 #ifdef __cplusplus
 }
 #endif

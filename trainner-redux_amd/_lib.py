@@ -124,6 +124,7 @@ SYMBOLS = {
     "tr_window_attention_bwd": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),
     "tr_pixel_shuffle": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64, View, C.c_float, C.c_void_p, C.c_int64]),
+    "tr_u8hwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
     "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),

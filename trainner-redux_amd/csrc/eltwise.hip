@@ -65,6 +65,27 @@ __global__ __launch_bounds__(256) void axpby_kernel(tr_view a, float sa, tr_view
 }
 
 
+// ---- feed: uint8 NHWC -> fp32 NCHW ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void u8hwc_to_nchw_kernel(const uint8_t* __restrict__ src, int n, int64_t hw, int c, float* __restrict__ dst, float3 mean,
+                                                             float3 istd) {
+    // one thread = 4 consecutive pixels of one image: 4*c contiguous source bytes, c float4 stores (one per plane).
+    // x / 255 is a correctly rounded division, bit-identical to the reference's `img.float() / 255.` (utils/img_util.py img2tensor)
+    const int64_t q = hw >> 2, total = (int64_t)n * q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nb = i / q, p0 = (i - nb * q) * 4;
+        const uint8_t* s = src + (nb * hw + p0) * c;
+        const float m[3] = {mean.x, mean.y, mean.z}, is[3] = {istd.x, istd.y, istd.z};
+        for (int ch = 0; ch < c; ++ch) {
+            float4 v;
+            v.x = ((float)s[ch] / 255.f - m[ch % 3]) * is[ch % 3];
+            v.y = ((float)s[c + ch] / 255.f - m[ch % 3]) * is[ch % 3];
+            v.z = ((float)s[2 * c + ch] / 255.f - m[ch % 3]) * is[ch % 3];
+            v.w = ((float)s[3 * c + ch] / 255.f - m[ch % 3]) * is[ch % 3];
+            *(float4*)(dst + (nb * c + ch) * hw + p0) = v;
+        }
+    }
+}
+
 // ---- SPAN parameter-free attention (span_arch.py:243-247) ----------------------------------------------------------------------
 __global__ __launch_bounds__(256) void span_gate_kernel(tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix, int c4, int v3, int vx, int vo,
                                                          int vo2) {
@@ -246,6 +267,16 @@ extern "C" int tr_axpby(void* stream, tr_view a, float sa, tr_view b, float sb, 
                        (int)tr::view_vec4_ok(a), (int)tr::view_vec4_ok(b), (int)tr::view_vec4_ok(out), mask, mask_slope, (int)tr::view_vec4_ok(mask),
                        sample_scale, pix_per_sample > 0 ? pix_per_sample : npix);
     return tr::launch_status("tr_axpby");
+}
+
+extern "C" int tr_u8hwc_to_nchw(void* stream, const uint8_t* src, int n, int h, int w, int c, float* dst, const float* mean3, const float* std3) {
+    TR_REQUIRE(src && dst && n > 0 && h > 0 && w > 0 && c > 0 && c <= 4, TR_EINVAL, "tr_u8hwc_to_nchw: bad arguments");
+    TR_REQUIRE(((int64_t)h * w) % 4 == 0 && ((uintptr_t)dst) % 16 == 0, TR_EALIGN, "tr_u8hwc_to_nchw: h*w must be a multiple of 4 and dst 16-byte aligned");
+    const float3 mean = mean3 ? make_float3(mean3[0], mean3[1], mean3[2]) : make_float3(0.f, 0.f, 0.f);
+    const float3 istd = std3 ? make_float3(1.f / std3[0], 1.f / std3[1], 1.f / std3[2]) : make_float3(1.f, 1.f, 1.f);
+    const int64_t hw = (int64_t)h * w;
+    hipLaunchKernelGGL(u8hwc_to_nchw_kernel, dim3(grid_for(n * (hw / 4))), dim3(256), 0, (hipStream_t)stream, src, n, hw, c, dst, mean, istd);
+    return tr::launch_status("tr_u8hwc_to_nchw");
 }
 
 extern "C" int tr_span_gate(void* stream, tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix) {

@@ -1,5 +1,6 @@
-"""Feed side of the hot path.  Round 1 ships the rank-sharding sampler; the paired
-dataset / pinned double-buffer loader are the next rows."""
+"""Feed side of the hot path: rank-sharding sampler, paired dataset, pinned double-buffer feed."""
 from .data_sampler import EnlargedSampler
+from .paired_image_dataset import PairedImageDataset
+from .prefetch import DevicePrefetcher, build_dataloader
 
-__all__ = ["EnlargedSampler"]
+__all__ = ["EnlargedSampler", "PairedImageDataset", "DevicePrefetcher", "build_dataloader"]

@@ -179,10 +179,22 @@ class SRModel:
 
     # ------------------------------------------------------------------ loop surface -------------------------
     def feed_data(self, data: dict) -> None:
+        """sr_model.py:434-450.  Besides the reference's fp32 CHW DataFeed this accepts uint8 (N, H, W, 3) patches (what
+        `data.DevicePrefetcher` ships: a quarter of the PCIe bytes) and converts them on the device with `tr_u8hwc_to_nchw`."""
         assert "lq" in data
-        self.lq = data["lq"].to(self.device, non_blocking=True)
+        self.lq = self._to_device_f32(data["lq"])
         if "gt" in data:
-            self.gt = data["gt"].to(self.device, non_blocking=True)
+            self.gt = self._to_device_f32(data["gt"])
+
+    def _to_device_f32(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.to(self.device, non_blocking=True)
+        if t.dtype == torch.uint8:
+            from .. import ops
+
+            out = torch.empty(t.shape[0], t.shape[3], t.shape[1], t.shape[2], dtype=torch.float32, device=self.device)
+            ops.u8hwc_to_nchw(t.contiguous(), out)
+            return out
+        return t
 
     def get_bare_model(self, net):
         return net

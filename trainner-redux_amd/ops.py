@@ -240,6 +240,16 @@ def axpby(a: L.View, sa: float, b: L.View, sb: float, out: L.View, npix: int, ma
                              sample_scale.data_ptr() if sample_scale is not None else None, pix_per_sample), "tr_axpby")
 
 
+def u8hwc_to_nchw(src: torch.Tensor, dst: torch.Tensor, mean=None, std=None):
+    """uint8 (N, H, W, C) device batch -> fp32 (N, C, H, W) in [0, 1] (optionally normalised)."""
+    _need_cuda(src, dst)
+    assert src.dtype == torch.uint8 and src.is_contiguous() and src.dim() == 4 and dst.dtype == torch.float32 and dst.is_contiguous()
+    n, h, w, c = src.shape
+    assert dst.shape == (n, c, h, w)
+    L.check(L.lib().tr_u8hwc_to_nchw(stream_ptr(), src.data_ptr(), n, h, w, c, dst.data_ptr(), _f3(mean) if mean is not None else None,
+                                     _f3(std) if std is not None else None), "tr_u8hwc_to_nchw")
+
+
 def span_gate(o3: L.View, x: L.View, out: L.View, out2: L.View | None, npix: int):
     L.check(L.lib().tr_span_gate(stream_ptr(), o3, x, out, out2 if out2 is not None else NULL_VIEW, npix), "tr_span_gate")
 
