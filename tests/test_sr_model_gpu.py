@@ -2,6 +2,7 @@
 
 fp32 compute: the weights after one full step (forward, all heads, backward, AdamW, EMA) must agree with the oracle to 1e-5;
 the log keys are the reference's (tests/test_models/test_sr_model.py:63-80)."""
+import os
 from collections import OrderedDict
 
 import pytest
@@ -194,3 +195,44 @@ def test_swinir_step_matches_oracle(cuda):
     e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in params.items())
     print("swinir weights after one step", e_w)
     assert e_w < 5e-4       # AdamW first-step sign sensitivity, as above
+
+
+def test_checkpoint_resume_is_bit_exact(cuda, tmp_path):
+    """save() + save_training_state() after 2 steps, a fresh model + load_network() + resume_training(), then step 3 on both:
+    generator, EMA and optimizer moments continue bit for bit (base_model.py:713-845, sr_model.py:1174-1205)."""
+    from trainner_redux_amd.models import SRModel
+
+    def make():
+        opt = _opt([dict(type="l1loss", loss_weight=1.0)], blocks=1)
+        opt.path.models = str(tmp_path / "models")
+        opt.path.resume_models = str(tmp_path / "models" / "resume_models")
+        opt.path.training_states = str(tmp_path / "training_states")
+        opt.train.scheduler = dict(type="MultiStepLR", milestones=[2], gamma=0.5)
+        return SRModel(opt)
+
+    a = make()
+    sd0 = {k: v.clone() for k, v in a.net_g.state_dict().items()}
+    for it in (1, 2):
+        lq, gt = _data(seed=it)
+        a.feed_data({"lq": lq, "gt": gt})
+        a.optimize_parameters(it, 0, True)
+        a.update_learning_rate(it, -1)
+    a.save(0, 2)
+    a.save_training_state(0, 2)
+    assert sorted(os.listdir(tmp_path / "models")) == ["net_g_ema_2.safetensors", "resume_models"]
+    b = make()
+    b.net_g.load_state_dict(sd0)
+    b.load_network(b.net_g, str(tmp_path / "models" / "resume_models" / "net_g_2.safetensors"))
+    b.load_network(b.net_g_ema.ema_model, str(tmp_path / "models" / "net_g_ema_2.safetensors"))
+    state = torch.load(tmp_path / "training_states" / "2.state", weights_only=False)      # our own file
+    assert state["iter"] == 2 and set(state["optimizers"][0]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    b.resume_training(state)
+    assert b.get_current_learning_rate() == a.get_current_learning_rate()
+    lq, gt = _data(seed=3)
+    for m in (a, b):
+        m.feed_data({"lq": lq, "gt": gt})
+        m.optimize_parameters(3, 0, True)
+    for (k, va), vb in zip(a.net_g.state_dict().items(), b.net_g.state_dict().values()):
+        assert torch.equal(va, vb), k
+    for va, vb in zip(a.net_g_ema.ema_model.state_dict().values(), b.net_g_ema.ema_model.state_dict().values()):
+        assert torch.equal(va, vb)

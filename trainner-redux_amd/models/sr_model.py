@@ -504,3 +504,31 @@ class SRModel:
             self.save_network(self.net_g, os.path.join(p.models, f"net_g_{current_iter}.{ext}"), fmt)
         if self.net_d is not None:
             self.save_network(self.net_d, os.path.join(p.resume_models or p.models, f"net_d_{current_iter}.{ext}"), fmt)
+
+    def save_training_state(self, epoch: int, current_iter: int) -> None:
+        """`{iter}.state` in the reference's layout (base_model.py:713-791): epoch, iter, optimizer and scheduler state dicts (the
+        optimizer's are torch.optim.AdamW-compatible per-parameter entries), EMA step.  No GradScaler entries: bf16 / fp32 only."""
+        p = self.opt.path
+        if p.training_states is None:
+            raise ValueError("opt.path.training_states is not set")
+        if current_iter == -1:
+            return
+        state = {"epoch": epoch, "iter": current_iter, "optimizers": [o.state_dict() for o in self.optimizers],
+                 "schedulers": [s.state_dict() for s in self.schedulers]}
+        if self.net_g_ema is not None:
+            state["ema_step"] = self.net_g_ema.step.detach().cpu().clone()
+        os.makedirs(p.training_states, exist_ok=True)
+        torch.save(state, os.path.join(p.training_states, f"{current_iter}.state"))
+
+    def resume_training(self, resume_state: dict) -> None:
+        """base_model.py:794-845."""
+        ro, rs = resume_state["optimizers"], resume_state["schedulers"]
+        assert len(ro) == len(self.optimizers), "Wrong lengths of optimizers"
+        assert len(rs) == len(self.schedulers), "Wrong lengths of schedulers"
+        for o, sd in zip(self.optimizers, ro):
+            o.load_state_dict(sd)
+        for s, sd in zip(self.schedulers, rs):
+            s.load_state_dict(sd)
+        if "ema_step" in resume_state and self.net_g_ema is not None:
+            self.net_g_ema.step.copy_(resume_state["ema_step"])
+            self.net_g_ema.initted.fill_(True)

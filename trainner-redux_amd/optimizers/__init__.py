@@ -44,6 +44,12 @@ class AdamW(torch.optim.Optimizer):
         self._grad_norm = None
         self._grad_scale_world = 1
 
+    def load_state_dict(self, state_dict) -> None:
+        """torch.optim.AdamW-compatible per-parameter state (`step`, `exp_avg`, `exp_avg_sq`): the loaded tensors are adopted by the
+        flat moment arenas at the next step()."""
+        super().load_state_dict(state_dict)
+        self._flat = {}
+
     # -- fused extras -------------------------------------------------------------------------------
     def set_step_extras(self, *, ema_arena: torch.Tensor | None = None, ema_decay: float = 1.0, clip: float = 0.0,
                         grad_norm: torch.Tensor | None = None) -> None:
@@ -86,8 +92,15 @@ class AdamW(torch.optim.Optimizer):
                     self._flat[key] = st
                     for p, _, _ in members:  # expose views so state_dict()/load_state_dict() see per-parameter state
                         off = p.data.storage_offset()
-                        self.state[p] = dict(step=torch.tensor(0.0), exp_avg=st["m"][off:off + p.numel()].view(p.shape),
-                                             exp_avg_sq=st["v"][off:off + p.numel()].view(p.shape))
+                        old = self.state.get(p) or {}
+                        views = dict(step=torch.tensor(0.0), exp_avg=st["m"][off:off + p.numel()].view(p.shape),
+                                     exp_avg_sq=st["v"][off:off + p.numel()].view(p.shape))
+                        if "exp_avg" in old:   # restored by load_state_dict() (resume_training, base_model.py:794-814): move it into the arenas
+                            views["exp_avg"].copy_(old["exp_avg"])
+                            views["exp_avg_sq"].copy_(old["exp_avg_sq"])
+                            views["step"] = torch.tensor(float(old["step"]))
+                            st["step"] = int(float(old["step"]))
+                        self.state[p] = views
                 st["step"] += 1
                 ema = self._ema_arena if (self._ema_arena is not None and self._ema_arena.numel() == pa.numel()) else None
                 ops.adamw_ema(pa, ga, st["m"], st["v"], ema, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
