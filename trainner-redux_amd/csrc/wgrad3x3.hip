@@ -304,7 +304,7 @@ struct Plan {
     size_t dw_floats, db_floats;
 };
 
-Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3) {
+Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3, int total_wgs = 768) {
     Plan p;
     p.ntx = (w + TW - 1) / TW;
     p.nty = (h + TH - 1) / TH;
@@ -312,7 +312,7 @@ Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3) {
     p.nchunks = (cin + CKW - 1) / CKW;
     p.cgw = cout > 32 ? 64 : 32;
     p.ncg = (cout + p.cgw - 1) / p.cgw;
-    int target = 768 / (p.nchunks * p.ncg);      // ~3 workgroups of 3 waves per CU
+    int target = total_wgs / (p.nchunks * p.ncg);      // resident workgroups (3 waves each) / (chunk, cg) pairs that walk the same tiles
     if (target < 1) target = 1;
     p.nslots = p.ntiles < target ? p.ntiles : target;
     // workgroup id = slot + nslots * (chunk + nchunks * cg) and ids are dealt round-robin to the 8 XCDs: with nslots a multiple of 8
@@ -369,7 +369,12 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     TR_REQUIRE(d->in_mode < TR_IN_FULL || d->pad_mode == TR_PAD_ZEROS, TR_EINVAL, "tr_wgrad3x3: full / valid modes take zero padding");
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_wgrad3x3: ksize must be 3 or 1");
     TR_REQUIRE(d->dw_ld == 0 || d->dw_ld >= d->cin, TR_EINVAL, "tr_wgrad3x3: dw_ld must be 0 or >= cin");
-    const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout, d->ksize);
+    // one round of RESIDENT workgroups (more would run as a half-empty second round): 3 per CU for the 32-wide bf16 variant
+    // (146 VGPRs), 2 for 64-wide bf16 and 32-wide f32, 1 for 64-wide f32; the workspace query assumes the largest (768)
+    static const int wgs_env = getenv("TRAINNER_WGRAD_WGS") ? atoi(getenv("TRAINNER_WGRAD_WGS")) : 0;
+    const bool wide = d->cout > 32;
+    const int wgs = wgs_env ? wgs_env : (d->compute == TR_BF16 ? (wide ? 512 : 768) : (wide ? 256 : 512));
+    const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout, d->ksize, wgs);
     TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
                "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
 
