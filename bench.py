@@ -36,13 +36,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s", "span", "span_s"],
                     help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles); "
-                         "span* = configs[4] (2x, batch 64 per GPU; bf16 here, the fp16 + GradScaler path is not built)")
+                         "span* = configs[4] (2x, batch 64 per GPU; add --compute f16 for its fp16 + loss-scaling mode)")
     ap.add_argument("--scale", type=int, default=None, help="default 4 (2 for span)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan = configs[1], 8 for swinir = configs[3] / SURVEY.md cfg4)")
     ap.add_argument("--lq", type=int, default=None, help="LR tile size (default 256 for esrgan, 64 for swinir)")
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
-    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "f32"], help="f16 = the reference's default AMP mode: fp16 operands + loss scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -65,7 +65,7 @@ def make_opt(args):
     elif args.losses == "l1+perceptualfp16":
         losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
     return parse_options_dict(dict(
-        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute == "bf16", amp_bf16=True,
+        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
         network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=args.scale),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
@@ -94,7 +94,7 @@ class ConvTimer:
             e0.record()
             orig(**kw)
             e1.record()
-            cd = "bf16" if kw["compute"] == L.BF16 else "f32"
+            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32"
             ks = kw.get("ksize", 3)
             flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * ks * ks * kw["cin"] * kw["cout"]
             timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1))
@@ -250,7 +250,7 @@ def main():
             "metric": f"training images/sec ({s}->{sc * s} {sc}x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SPAN" if args.arch.startswith("span") else "SwinIR"),
             "value": n * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.compute if args.compute == "bf16" else "f32", "data": "synthetic",
+            "dtype": args.compute, "data": "synthetic",
             "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
                                    + f" {args.losses} {args.compute}, {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
@@ -260,7 +260,7 @@ def main():
             agg = timer.summary()
             key = max(agg, key=lambda k: agg[k][2])
             cnt, flops, msum = agg[key]
-            peak = 2500.0 if key[0] == "bf16" else 157.3
+            peak = 157.3 if key[0] == "f32" else 2500.0
             ach = flops / (msum * 1e-3) / 1e12
             traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
             try:

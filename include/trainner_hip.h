@@ -34,7 +34,7 @@ extern "C" {
 
 #define TR_ABI_VERSION 1
 
-enum { TR_F32 = 0, TR_BF16 = 1 };
+enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
 enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3, TR_ACT_SILU = 4 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
@@ -45,7 +45,7 @@ enum { TR_GAN_VANILLA = 0, TR_GAN_LSGAN = 1, TR_GAN_WGAN = 2, TR_GAN_WGAN_SOFTPL
 /* channel-slice view of an NHWC buffer (ptr == NULL means "absent") */
 typedef struct tr_view {
     void*   ptr;      /* base of the NHWC buffer                                  */
-    int32_t dtype;    /* TR_F32 | TR_BF16                                          */
+    int32_t dtype;    /* TR_F32 | TR_BF16 | TR_F16                                 */
     int32_t cstride;  /* channels per pixel record of the underlying buffer        */
     int32_t coff;     /* first channel of the view                                 */
     int32_t c;        /* channels in the view                                      */
@@ -72,14 +72,14 @@ size_t      tr_conv_packed_bytes(int cin, int cout, int compute, int ksize);
  *   v *= (mask > 0 ? 1 : mask_slope)                      (only if mask.ptr  != NULL)
  *   out = (out.dtype) v ; out2 = (out2.dtype)(v*out2_scale)   (out2 optional)
  *
- * compute = TR_BF16: in.dtype must be TR_BF16, operands bf16, fp32 accumulate
- *           (v_mfma_f32_32x32x16_bf16); compute = TR_F32: in.dtype TR_F32, exact fp32
+ * compute = TR_BF16 / TR_F16: in.dtype must equal it, 16-bit operands, fp32 accumulate
+ *           (v_mfma_f32_32x32x16_bf16 / _f16); compute = TR_F32: in.dtype TR_F32, exact fp32
  *           (v_mfma_f32_32x32x2_f32).  Epilogue arithmetic is always fp32.
  */
 typedef struct tr_conv3x3_desc {
     int32_t n, h, w;          /* OUTPUT batch / height / width                                */
     int32_t cin, cout;
-    int32_t compute;          /* TR_F32 | TR_BF16                                             */
+    int32_t compute;          /* TR_F32 | TR_BF16 | TR_F16                                    */
     int32_t in_mode;          /* TR_IN_DIRECT (input n x h x w) | TR_IN_NEAREST2X (n x h/2 x w/2) |
                                  TR_IN_FULL (input n x (h-2) x (w-2): 'full' correlation, out(y,x) = sum in(y+ky-2, x+kx-2) W,
                                  i.e. the input gradient of a conv over an explicitly padded image) |
@@ -132,7 +132,7 @@ typedef struct tr_pack_seg {
     int32_t dst_cin, dst_cout;
     int32_t dst_o_off, dst_i_off;   /* in the packed conv's (cout, cin) index space           */
     int32_t transpose;
-    int32_t compute;          /* TR_F32 | TR_BF16                                             */
+    int32_t compute;          /* TR_F32 | TR_BF16 | TR_F16                                    */
     int32_t ksize;            /* 3 or 1: src is OI(ksize)(ksize)                              */
     int32_t reserved;
     int64_t first;            /* exclusive prefix sum of o_cnt*i_cnt*9 over segments (host-filled) */
@@ -315,6 +315,8 @@ typedef struct tr_adamw_desc {
     float   clip;                       /* <= 0: no clipping */
     const float* grad_norm;             /* device scalar from tr_sumsq (needed if clip > 0) */
     int32_t zero_grad;
+    float   inv_scale;                  /* 0 or 1: gradients as they are; otherwise g *= inv_scale first (GradScaler.unscale_, sr_model.py:688-690)
+                                           and the clip coefficient uses grad_norm * inv_scale */
 } tr_adamw_desc;
 int tr_adamw_ema(void* stream, const tr_adamw_desc* d);
 

@@ -1,0 +1,125 @@
+"""fp16 compute + loss scaling (the reference's default AMP mode: use_amp without amp_bf16, GradScaler at
+sr_model.py:188-191,681-719).  Kernels use v_mfma_f32_32x32x16_f16 with fp32 accumulation; the oracle policy `f16_ops` rounds the same
+operands to fp16.  Tolerances as for bf16 but tighter where fp16's 10-bit mantissa allows: forward <= 3e-3 vs the same-policy oracle."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+
+
+def test_esrgan_fp16_vs_policy_oracle(cuda):
+    from oracle import esrgan as OE, losses as OL
+    from oracle.precision import F16_OPS
+    from trainner_redux_amd.archs import build_network
+
+    hp = OE.esrgan_hparams(scale=4, num_blocks=2)
+    sd = OE.init_state_dict(hp, 0)
+    net = build_network({"type": "esrgan", "scale": 4, "num_blocks": 2})
+    net.load_state_dict(sd)
+    net = net.to(cuda).train()
+    net.compute_dtype = torch.float16
+    g = torch.Generator().manual_seed(2)
+    x, gt = torch.rand(2, 3, 24, 40, generator=g), torch.rand(2, 3, 96, 160, generator=g)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    out_ref = OE.forward(params, x, hp, F16_OPS)
+    loss = OL.l1(out_ref, gt)
+    # loss scaling on BOTH sides: d(loss)/d(out) ~ 1e-6 underflows fp16 operands (that is what GradScaler exists for)
+    grads = torch.autograd.grad(loss * 1024.0, [out_ref, *params.values()])
+    out = net.forward_hip(x.to(cuda), train=True)
+    e = rel_l2(out.cpu(), out_ref.detach())
+    net.backward_hip(grads[0].to(cuda))
+    cs = {k: cosine(p.grad.cpu(), gr) for (k, p), gr in zip(net.state_dict(keep_vars=True).items(), grads[1:])}
+    worst = min(cs, key=cs.get)
+    print(f"esrgan fp16: fwd {e:.2e}; worst grad cosine {worst} {cs[worst]:.4f}")
+    assert e < 3e-3 and cs[worst] > 0.99
+
+
+def test_swinir_and_span_fp16_forward(cuda):
+    from oracle import span as OSP, swinir as OW
+    from oracle.precision import F16_OPS
+    from trainner_redux_amd.archs import build_network
+
+    hp = OW.hparams("swinir_s", scale=4, depths=[2, 2], num_heads=[6, 6])
+    sd = OW.init_state_dict(hp, 0)
+    net = build_network({"type": "swinir_s", "scale": 4, "depths": [2, 2], "num_heads": [6, 6]})
+    net.load_state_dict(sd, strict=False)
+    net = net.to(cuda).train()
+    net.compute_dtype = torch.float16
+    x = torch.rand(2, 3, 16, 24, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = OW.forward(sd, x, hp, F16_OPS)
+    out = net.forward_hip(x.to(cuda), train=True, keep_masks={})
+    e_sw = rel_l2(out.cpu(), ref)
+    net.backward_hip(torch.randn_like(out) * 64.0)          # MFMA attention backward in fp16 runs and stays finite
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    import os
+    e = torch.load(os.path.join(os.path.dirname(__file__), "golden", "span.pt"), weights_only=True)["fc12_x4_norm"]
+    kw = e["kwargs"]
+    hp2 = OSP.hparams(feature_channels=kw["feature_channels"], scale=kw["upscale"], norm=kw["norm"], img_range=kw["img_range"])
+    net2 = build_network({"type": "span", "feature_channels": 12, "scale": 4, "norm": True, "img_range": 255.0})
+    net2.load_state_dict(e["state"])
+    net2 = net2.to(cuda).eval()
+    net2.compute_dtype = torch.float16
+    with torch.no_grad():
+        ref2 = OSP.forward({k: v for k, v in e["state"].items()}, e["x"], hp2, F16_OPS, train=True)
+        out2 = net2(e["x"].to(cuda))
+    e_sp = rel_l2(out2.cpu(), ref2)
+    print(f"fp16 forward vs f16-policy oracle: swinir_s {e_sw:.2e}, span {e_sp:.2e}")
+    assert e_sw < 3e-3 and e_sp < 3e-3
+
+
+def test_fp16_step_with_loss_scaling_and_overflow_skip(cuda):
+    """use_amp without amp_bf16: the step runs with scale 65536 and lands where the f16-policy oracle step lands; an overflowing
+    step (scale forced to 2^60) is skipped: weights and Adam moments untouched, scale halved, scheduler not advanced."""
+    from oracle import esrgan as OE, losses as OL, step as OS
+    from oracle.precision import F16_OPS
+    from tests.test_sr_model_gpu import _data, _opt
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], use_amp=True, blocks=1)
+    opt.amp_bf16 = False
+    model = SRModel(opt)
+    assert model.compute_dtype == torch.float16 and model.scaler_g.enabled and model.scaler_g.scale == 65536.0
+    hp = OE.esrgan_hparams(scale=4, num_blocks=1)
+    sd = OE.init_state_dict(hp, 0)
+    model.net_g.load_state_dict(sd)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    lq, gt = _data(seed=7)
+    _, ld, _, _ = OS.generator_step(params, lambda p, x: OE.forward(p, x, hp, F16_OPS), OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, None)
+    # the oracle's weights come from a SCALED loss as well (unscaled fp16 gradients sit in the subnormals); a first Adam step is
+    # invariant to the scale up to eps
+    params2 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost2 = OS.AdamWState(OrderedDict((k, v.data) for k, v in params2.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    OS.generator_step(params2, lambda p, x: OE.forward(p, x, hp, F16_OPS), OrderedDict(l_g_l1=(lambda o, t: OL.l1(o, t) * 65536.0, 1.0)), lq, gt, ost2, None)
+    params = params2
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 2e-3 * float(ld["l_g_l1"])
+    assert abs(log["grad_norm_g"] - float(ld["grad_norm_g"])) < 0.1 * float(ld["grad_norm_g"])       # logged AFTER unscale_ (oracle value: unscaled, subnormal-noisy)
+    moved = max(rel_l2(p.detach().cpu() - sd[k], params[k].data - sd[k]) for k, p in model.net_g.state_dict().items() if p.ndim == 4)
+    print("fp16 step: update direction rel-L2 vs f16-policy oracle (first AdamW step = lr * sign-like):", moved)
+    assert moved < 0.35          # sign flips of near-zero gradients dominate a first Adam step (see test_sr_model_gpu.py)
+    # ---- overflow: skip
+    before = {k: v.clone() for k, v in model.net_g.state_dict().items()}
+    model.scaler_g.scale = 2.0 ** 60
+    model.reset_current_log()
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(2, 0, True)
+    assert model.optimizers_skipped[0] and model.scaler_g.scale == 2.0 ** 59
+    for k, v in model.net_g.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    g_arena = model.net_g.flat_parameters()[1]
+    assert float(g_arena.abs().sum()) == 0.0           # the overflowed gradients are dropped, not accumulated

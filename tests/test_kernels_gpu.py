@@ -30,6 +30,15 @@ def bf(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+def ct(L, name):
+    """compute-dtype name -> (C-ABI code, torch dtype, operand rounding)"""
+    if name == "f32":
+        return L.F32, torch.float32, (lambda t: t)
+    if name == "bf16":
+        return L.BF16, torch.bfloat16, bf
+    return L.F16, torch.float16, (lambda t: t.to(torch.float16).to(torch.float32))
+
+
 def pack(ops, L, w, cin, cout, compute, dev, transpose=False):
     buf = torch.zeros(ops.packed_bytes(cin, cout, compute), dtype=torch.uint8, device=dev)
     plan = ops.PackPlan(dev)
@@ -38,7 +47,7 @@ def pack(ops, L, w, cin, cout, compute, dev, transpose=False):
     return buf
 
 
-@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 64, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 3),
                                    (1, 9, 31, 32, 128)])
 def test_conv3x3_forward(cuda, compute_name, shape):
@@ -46,14 +55,12 @@ def test_conv3x3_forward(cuda, compute_name, shape):
     from trainner_redux_amd import _lib as L, ops
 
     n, h, w, cin, cout = shape
-    compute = L.F32 if compute_name == "f32" else L.BF16
-    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    compute, dt, rnd = ct(L, compute_name)
     g = torch.Generator().manual_seed(1234 + cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
     b = torch.randn(cout, generator=g)
-    if compute == L.BF16:
-        x, wt = bf(x), bf(wt)
+    x, wt = rnd(x), rnd(wt)
     ref = F.leaky_relu(F.conv2d(x, wt, b, padding=1), 0.2)
     xd = nhwc(x).to(cuda, dt)
     wp = pack(ops, L, wt.to(cuda), cin, cout, compute, cuda)
@@ -179,19 +186,17 @@ def test_conv3x3_input_gradient_via_transposed_pack_and_mask(cuda, compute_name)
     assert rel_l2(nchw(out.cpu()), ref) < 2e-6
 
 
-@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 70, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 8)])
 def test_wgrad3x3(cuda, compute_name, shape):
     from trainner_redux_amd import _lib as L, ops
 
-    compute = L.F32 if compute_name == "f32" else L.BF16
-    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    compute, dt, rnd = ct(L, compute_name)
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(21 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
     gy = torch.randn(n, cout, h, w, generator=g)
-    if compute == L.BF16:
-        x, gy = bf(x), bf(gy)
+    x, gy = rnd(x), rnd(gy)
     ref_w = torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), gy, padding=1)
     ref_b = gy.sum(dim=(0, 2, 3))
     ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4, dtype=torch.float32, device=cuda)
@@ -367,7 +372,7 @@ def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
     assert rel_l2(out2.cpu(), img.grad) < 3e-6
 
 
-@pytest.mark.parametrize("compute_name", ["f32", "bf16"])
+@pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180), (2, 18, 32, 192, 540), (1, 8, 32, 192, 256),
                                   (1, 6, 32, 192, 300), (2, 16, 32, 192, 360), (1, 9, 32, 64, 120), (1, 8, 48, 64, 60), (2, 5, 32, 64, 24)])
 def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
@@ -375,8 +380,7 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     forward with exact GELU (+ pre-activation side output), input gradient with the GELU-derivative mask, weight/bias gradient."""
     from trainner_redux_amd import _lib as L, ops
 
-    compute = L.F32 if compute_name == "f32" else L.BF16
-    dt = torch.float32 if compute == L.F32 else torch.bfloat16
+    compute, dt, rnd = ct(L, compute_name)
     n, h, w, kp, nout = dims            # kp: padded input width (multiple of 32), k = kp - 12 real inputs
     k = kp - 12 if kp > 64 else kp - 4
     g = torch.Generator().manual_seed(kp + nout)
@@ -384,16 +388,14 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     wt = torch.randn(nout, k, generator=g) / math.sqrt(k)
     b = torch.randn(nout, generator=g)
     keep = torch.tensor([1.25, 0.0][:n])
-    if compute == L.BF16:
-        x, wt = bf(x), bf(wt)
+    x, wt = rnd(x), rnd(wt)
     xr = x.clone().requires_grad_(True)
     wr = wt.clone().requires_grad_(True)
     br = b.clone().requires_grad_(True)
     pre = F.linear(xr, wr, br)
     y = F.gelu(pre) * keep.repeat_interleave(h * w).view(-1, 1)
     gy = torch.randn(y.shape, generator=g)
-    if compute == L.BF16:
-        gy = bf(gy)
+    gy = rnd(gy)
     y.backward(gy)
     xd = torch.zeros(n, h, w, kp, dtype=dt, device=cuda)
     xd[..., :k] = x.view(n, h, w, k).to(cuda, dt)
@@ -419,8 +421,7 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     pre_det = pre.detach().clone().requires_grad_(True)
     F.gelu(pre_det).sum().backward()
     gpre = gy * keep.repeat_interleave(h * w).view(-1, 1) * pre_det.grad
-    if compute == L.BF16:
-        gpre = bf(gpre)
+    gpre = rnd(gpre)
     gpd = torch.zeros(n, h, w, nop, dtype=dt, device=cuda)
     gpd[..., :nout] = gpre.view(n, h, w, nout).to(cuda, dt)
     gx = torch.zeros(n, h, w, kp, dtype=torch.float32, device=cuda)

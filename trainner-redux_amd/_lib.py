@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 IN_DIRECT, IN_NEAREST2X, IN_FULL, IN_VALID = 0, 1, 2, 3
@@ -93,7 +93,7 @@ class AdamWDesc(C.Structure):
         ("numel", C.c_int64),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
         ("bias_corr1", C.c_float), ("bias_corr2", C.c_float), ("ema_decay", C.c_float), ("clip", C.c_float),
-        ("grad_norm", C.c_void_p), ("zero_grad", C.c_int32),
+        ("grad_norm", C.c_void_p), ("zero_grad", C.c_int32), ("inv_scale", C.c_float),
     ]
 
 

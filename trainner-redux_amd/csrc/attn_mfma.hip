@@ -25,6 +25,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2n;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2n;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef unsigned u32x4a __attribute__((ext_vector_type(4), aligned(4)));   // head slices start at 4-byte boundaries (even head_dim), not 16
 
 constexpr int WS = 8, WT = 64, NTAB = (2 * WS - 1) * (2 * WS - 1);
@@ -38,14 +40,22 @@ __device__ __forceinline__ void wave_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ unsigned pack2(float a, float b) {
+template <int CT>
+__device__ __forceinline__ unsigned pack2(float a, float b) {   // two fp32 -> packed 16-bit operands (bf16 or fp16, round to nearest even)
     const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n));
+    if constexpr (CT == TR_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2n));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2n));
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int j, float mul) {   // accumulator registers 8j .. 8j+7 -> bf16 operand
-    const unsigned a = pack2(v[8 * j + 0] * mul, v[8 * j + 1] * mul), b = pack2(v[8 * j + 2] * mul, v[8 * j + 3] * mul);
-    const unsigned c = pack2(v[8 * j + 4] * mul, v[8 * j + 5] * mul), d = pack2(v[8 * j + 6] * mul, v[8 * j + 7] * mul);
+template <int CT>
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int j, float mul) {   // accumulator registers 8j .. 8j+7 -> 16-bit operand
+    const unsigned a = pack2<CT>(v[8 * j + 0] * mul, v[8 * j + 1] * mul), b = pack2<CT>(v[8 * j + 2] * mul, v[8 * j + 3] * mul);
+    const unsigned c = pack2<CT>(v[8 * j + 4] * mul, v[8 * j + 5] * mul), d = pack2<CT>(v[8 * j + 6] * mul, v[8 * j + 7] * mul);
     return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+}
+template <int CT>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (CT == TR_BF16) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ int region(int s, int n, int shift) { return s < n - WS ? 0 : (s < n - shift ? 1 : 2); }
 __device__ __forceinline__ int64_t token_of(const AttnArgs& a, int bb, int wy, int wx, int i) {
@@ -86,13 +96,14 @@ __device__ __forceinline__ bf16x8 col_frag_lds(const char* tile, int base, int l
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 // accumulator tile (rows = head channels, column = this lane's token) -> row `row` of a swizzled LDS tile, as bf16
+template <int CT>
 __device__ __forceinline__ void acc_to_tile(char* tile, int row, int hh, const f32x16& v, float mul) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        *(uint2*)(tile + tile_off(row, 16 * g + 8 * hh)) = make_uint2(pack2(v[4 * g] * mul, v[4 * g + 1] * mul), pack2(v[4 * g + 2] * mul, v[4 * g + 3] * mul));
+        *(uint2*)(tile + tile_off(row, 16 * g + 8 * hh)) = make_uint2(pack2<CT>(v[4 * g] * mul, v[4 * g + 1] * mul), pack2<CT>(v[4 * g + 2] * mul, v[4 * g + 3] * mul));
 }
 
-#define MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#define MFMA(A, B, C) mfma16<CT>(A, B, C)
 
 // scores of one orientation: x = s * scale + bias(table) (+ shift mask); the bias index is (qy - ky + 7) * 15 + (qx - kx + 7)
 struct MaskCtx { bool on; unsigned ym, xm; };
@@ -112,6 +123,7 @@ __device__ __forceinline__ MaskCtx mask_ctx(const AttnArgs& a, int wy, int wx, i
 __device__ __forceinline__ int reg_of(const MaskCtx& m, int y, int x) { return (int)((m.ym >> (2 * y)) & 3u) * 3 + (int)((m.xm >> (2 * x)) & 3u); }
 
 // ============================================================ forward ==========================================================
+template <int CT>
 __global__ __launch_bounds__(256, 2) void window_attn_fwd_mfma_kernel(AttnArgs a, int ntasks) {
     constexpr int WAVE_LDS = TILE + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -197,11 +209,11 @@ __global__ __launch_bounds__(256, 2) void window_attn_fwd_mfma_kernel(AttnArgs a
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    ot[qt] = MFMA(col_frag_lds(tv, kt * 32 + 16 * j + 4 * hh, l), pack8(st[kt][qt], j, inv), ot[qt]);
+                    ot[qt] = MFMA(col_frag_lds(tv, kt * 32 + 16 * j + 4 * hh, l), pack8<CT>(st[kt][qt], j, inv), ot[qt]);
         }
         wave_sync();                                  // every lane is done reading V: the tile becomes the output tile
-        acc_to_tile(tv, lr, hh, ot[0], 1.f);
-        acc_to_tile(tv, 32 + lr, hh, ot[1], 1.f);
+        acc_to_tile<CT>(tv, lr, hh, ot[0], 1.f);
+        acc_to_tile<CT>(tv, 32 + lr, hh, ot[1], 1.f);
         wave_sync();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -213,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_fwd_mfma_kernel(AttnArgs a
 
 // ============================================================ backward =========================================================
 // ~300 live VGPRs (four 32x32 accumulator pairs + the bias-gradient sums): one workgroup per CU with the 512-register budget
+template <int CT>
 __global__ __launch_bounds__(256, 1) void window_attn_bwd_mfma_kernel(AttnArgs a, int ntasks, float* __restrict__ dbpart) {
     constexpr int WAVE_LDS = 4 * TILE + 768 + 1024;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,8 +351,8 @@ __global__ __launch_bounds__(256, 1) void window_attn_bwd_mfma_kernel(AttnArgs a
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) dq = MFMA(col_frag_lds(tk, kt * 32 + 16 * j + 4 * hh, l), pack8(dp[kt], j, 1.f), dq);
-            acc_to_tile(to, qt * 32 + lr, hh, dq, sc);
+                for (int j = 0; j < 2; ++j) dq = MFMA(col_frag_lds(tk, kt * 32 + 16 * j + 4 * hh, l), pack8<CT>(dp[kt], j, 1.f), dq);
+            acc_to_tile<CT>(to, qt * 32 + lr, hh, dq, sc);
             __builtin_amdgcn_sched_barrier(0);     // keep the two query tiles' live ranges apart (VGPR budget)
         }
         wave_sync();
@@ -394,12 +407,12 @@ __global__ __launch_bounds__(256, 1) void window_attn_bwd_mfma_kernel(AttnArgs a
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    dv = MFMA(col_frag_lds(tg, qt * 32 + 16 * j + 4 * hh, l), pack8(s[qt], j, 1.f), dv);
-                    dk = MFMA(col_frag_lds(tq, qt * 32 + 16 * j + 4 * hh, l), pack8(dp[qt], j, 1.f), dk);
+                    dv = MFMA(col_frag_lds(tg, qt * 32 + 16 * j + 4 * hh, l), pack8<CT>(s[qt], j, 1.f), dv);
+                    dk = MFMA(col_frag_lds(tq, qt * 32 + 16 * j + 4 * hh, l), pack8<CT>(dp[qt], j, 1.f), dk);
                 }
             wave_sync();                              // the previous pieces have left the staging tile
-            acc_to_tile(to, lr, hh, dk, sc);
-            acc_to_tile(to, 32 + lr, hh, dv, 1.f);
+            acc_to_tile<CT>(to, lr, hh, dk, sc);
+            acc_to_tile<CT>(to, 32 + lr, hh, dv, 1.f);
             wave_sync();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -480,9 +493,9 @@ bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
     auto ok = [&](const tr_view& v, int width) {
         // bf16, 4-byte aligned head slices, and the last 16-byte piece of the last head stays inside the row
         const int last = width - a.hd + (a.hd + 7) / 8 * 8;
-        return v.ptr && v.dtype == TR_BF16 && v.cstride % 2 == 0 && v.coff % 2 == 0 && v.coff + last <= v.cstride && ((uintptr_t)v.ptr % 4) == 0;
+        return v.ptr && v.dtype == a.qkv.dtype && v.cstride % 2 == 0 && v.coff % 2 == 0 && v.coff + last <= v.cstride && ((uintptr_t)v.ptr % 4) == 0;
     };
-    if (a.hd % 2 != 0 || a.hd > 32 || a.nh > 64) return false;
+    if (a.hd % 2 != 0 || a.hd > 32 || a.nh > 64 || (a.qkv.dtype != TR_BF16 && a.qkv.dtype != TR_F16)) return false;
     if (!ok(a.qkv, 3 * a.c)) return false;
     if (!bwd) return ok(a.out, a.c);
     return ok(a.dout, a.c) && ok(a.dqkv, 3 * a.c);
@@ -491,7 +504,8 @@ bool attn_mfma_ok(const AttnArgs& a, bool bwd) {
 int launch_window_attn_fwd_mfma(hipStream_t st, const AttnArgs& a) {
     const int ntasks = a.b * (a.h / WS) * (a.w / WS) * a.nh;
     const size_t lds = 4 * (size_t)(TILE + 1024);
-    hipLaunchKernelGGL(window_attn_fwd_mfma_kernel, dim3(grid_for_tasks(ntasks, a.nh, FWD_CAP)), dim3(256), lds, st, a, ntasks);
+    if (a.qkv.dtype == TR_BF16) hipLaunchKernelGGL(window_attn_fwd_mfma_kernel<TR_BF16>, dim3(grid_for_tasks(ntasks, a.nh, FWD_CAP)), dim3(256), lds, st, a, ntasks);
+    else hipLaunchKernelGGL(window_attn_fwd_mfma_kernel<TR_F16>, dim3(grid_for_tasks(ntasks, a.nh, FWD_CAP)), dim3(256), lds, st, a, ntasks);
     return tr::launch_status("tr_window_attention(mfma)");
 }
 
@@ -504,12 +518,14 @@ int launch_window_attn_bwd_mfma(hipStream_t st, const AttnArgs& a, float* dtable
     const size_t lds = 4 * (size_t)(4 * TILE + 768 + 1024);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)window_attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)window_attn_bwd_mfma_kernel<TR_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)window_attn_bwd_mfma_kernel<TR_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const int grid = grid_for_tasks(ntasks, a.nh, BWD_CAP);
     float* part = dtable ? a.dbias_ws : nullptr;
-    hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3(grid), dim3(256), lds, st, a, ntasks, part);
+    if (a.qkv.dtype == TR_BF16) hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<TR_BF16>, dim3(grid), dim3(256), lds, st, a, ntasks, part);
+    else hipLaunchKernelGGL(window_attn_bwd_mfma_kernel<TR_F16>, dim3(grid), dim3(256), lds, st, a, ntasks, part);
     int rc = tr::launch_status("tr_window_attention_bwd(mfma)");
     if (rc || !dtable) return rc;
     float* full = part + (size_t)grid * 4 * WT * WT;

@@ -26,7 +26,7 @@ inline int launch_status(const char* what) {
     return 0;
 }
 
-__host__ __device__ inline int esize(int dtype) { return dtype == TR_BF16 ? 2 : 4; }
+__host__ __device__ inline int esize(int dtype) { return dtype == TR_F32 ? 4 : 2; }
 
 // ---- device-side scalar conversions -------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(unsigned short b) {
@@ -38,14 +38,20 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, b);
 }
 
+__device__ __forceinline__ float f16_to_f32(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned short f32_to_f16(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }   // RNE, saturates to inf
+// 16-bit storage (bf16 / fp16) <-> fp32
+__device__ __forceinline__ float h_to_f32(unsigned short h, int dtype) { return dtype == TR_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
+__device__ __forceinline__ unsigned short f32_to_h(float f, int dtype) { return dtype == TR_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
+
 __device__ __forceinline__ float view_load(const tr_view& v, int64_t pix, int c) {
     int64_t idx = pix * v.cstride + v.coff + c;
-    if (v.dtype == TR_BF16) return bf16_to_f32(((const unsigned short*)v.ptr)[idx]);
+    if (v.dtype != TR_F32) return h_to_f32(((const unsigned short*)v.ptr)[idx], v.dtype);
     return ((const float*)v.ptr)[idx];
 }
 __device__ __forceinline__ void view_store(const tr_view& v, int64_t pix, int c, float x) {
     int64_t idx = pix * v.cstride + v.coff + c;
-    if (v.dtype == TR_BF16) ((unsigned short*)v.ptr)[idx] = f32_to_bf16(x);
+    if (v.dtype != TR_F32) ((unsigned short*)v.ptr)[idx] = f32_to_h(x, v.dtype);
     else ((float*)v.ptr)[idx] = x;
 }
 
@@ -62,6 +68,12 @@ __device__ __forceinline__ float4 view_load4(const tr_view& v, int64_t pix, int 
         } else {
             r.x = bf16_to_f32(p[0]); r.y = bf16_to_f32(p[1]); r.z = bf16_to_f32(p[2]); r.w = bf16_to_f32(p[3]);
         }
+    } else if (v.dtype == TR_F16) {
+        const unsigned short* p = (const unsigned short*)v.ptr + idx;
+        unsigned short q[4];
+        if (vec) { const uint2 u = *(const uint2*)p; q[0] = u.x & 0xffffu; q[1] = u.x >> 16; q[2] = u.y & 0xffffu; q[3] = u.y >> 16; }
+        else { q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3]; }
+        r.x = f16_to_f32(q[0]); r.y = f16_to_f32(q[1]); r.z = f16_to_f32(q[2]); r.w = f16_to_f32(q[3]);
     } else {
         const float* p = (const float*)v.ptr + idx;
         if (vec) r = *(const float4*)p;
@@ -71,9 +83,9 @@ __device__ __forceinline__ float4 view_load4(const tr_view& v, int64_t pix, int 
 }
 __device__ __forceinline__ void view_store4(const tr_view& v, int64_t pix, int c, float4 x, bool vec) {
     int64_t idx = pix * v.cstride + v.coff + c;
-    if (v.dtype == TR_BF16) {
+    if (v.dtype != TR_F32) {
         unsigned short* p = (unsigned short*)v.ptr + idx;
-        unsigned short a = f32_to_bf16(x.x), b = f32_to_bf16(x.y), c2 = f32_to_bf16(x.z), d = f32_to_bf16(x.w);
+        unsigned short a = f32_to_h(x.x, v.dtype), b = f32_to_h(x.y, v.dtype), c2 = f32_to_h(x.z, v.dtype), d = f32_to_h(x.w, v.dtype);
         if (vec) { uint2 u; u.x = (unsigned)a | ((unsigned)b << 16); u.y = (unsigned)c2 | ((unsigned)d << 16); *(uint2*)p = u; }
         else { p[0] = a; p[1] = b; p[2] = c2; p[3] = d; }
     } else {
@@ -106,8 +118,8 @@ struct PackGeom {
 };
 __host__ __device__ inline PackGeom pack_geom(int cin, int cout, int compute) {
     PackGeom g;
-    g.ck = compute == TR_BF16 ? 32 : 16;
-    g.eps = compute == TR_BF16 ? 8 : 4;
+    g.ck = compute == TR_F32 ? 16 : 32;
+    g.eps = compute == TR_F32 ? 4 : 8;
     g.cgw = cout > 32 ? 64 : 32;
     g.ncg = (cout + g.cgw - 1) / g.cgw;
     g.nchunks = (cin + g.ck - 1) / g.ck;

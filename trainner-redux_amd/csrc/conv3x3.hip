@@ -24,6 +24,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -61,7 +62,7 @@ __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, 
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int slot = q * 2 + lh;
-            if constexpr (CT == TR_BF16) {
+            if constexpr (CT != TR_F32) {
                 bf16x8 wa[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -73,8 +74,10 @@ __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, 
                     const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
                     const bf16x8 xb = *(const bf16x8*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb, acc[r][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (CT == TR_BF16) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb, acc[r][t], 0, 0, 0);
+                        else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[t]), __builtin_bit_cast(f16x8, xb), acc[r][t], 0, 0, 0);
+                    }
                 }
             } else {
                 f32x4 wa[NT];
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
     constexpr int HALO_BYTES = HALO_PIX * 64;
     constexpr int CGW = NT * 32;
     constexpr int W_ITEMS = KS * KS * CGW * 4;
-    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int ES = CT == TR_F32 ? 4 : 2;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
     constexpr int HALO_IT = (HALO_ITEMS + NTHREADS - 1) / NTHREADS;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
     constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr int W_BYTES = W_IT * NTHREADS * 16;
     constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;
-    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int ES = CT == TR_F32 ? 4 : 2;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
     constexpr unsigned OOB = 0x7fffff00u;              // beyond any num_records: the buffer load returns 0
@@ -498,7 +501,7 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
     // resident workgroups: 2 per CU, or 3 for the 8-row / 32-channel tile (164 VGPRs, 40 KB LDS) -- measured +15 % on the thin
     // RDB convs (cin <= 96), whose K loop is too short to hide the load latency with two workgroups
     static const int persist_env = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 0;
-    const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && CT == TR_BF16) ? 768 : 512);
+    const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && CT != TR_F32) ? 768 : 512);
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
     const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
     hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R, KS>), dim3(grid), dim3(NTHREADS), lds, st, a);
@@ -516,7 +519,7 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
 template <int CT, int NCG>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(ConvArgs a, int nblk) {
     constexpr int R = 2, NT = NCG;
-    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int ES = CT == TR_F32 ? 4 : 2;
     constexpr int EPS = 16 / ES;
     constexpr int CK = 64 / ES;
     constexpr int X_BYTES = 128 * 64;
@@ -616,7 +619,7 @@ int launch_dma(hipStream_t st, const ConvArgs& a, int ncg) {
 
 bool view_ok(const tr_view& v, int c_needed) {
     if (!v.ptr) return true;
-    return (v.dtype == TR_F32 || v.dtype == TR_BF16) && v.cstride > 0 && v.coff >= 0 && v.coff + c_needed <= v.cstride &&
+    return (v.dtype == TR_F32 || v.dtype == TR_BF16 || v.dtype == TR_F16) && v.cstride > 0 && v.coff >= 0 && v.coff + c_needed <= v.cstride &&
            v.c >= c_needed;
 }
 
@@ -626,11 +629,11 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_conv3x3: null descriptor");
     TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, TR_EINVAL,
                "tr_conv3x3: bad dims n=%d h=%d w=%d cin=%d cout=%d", d->n, d->h, d->w, d->cin, d->cout);
-    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16, TR_EINVAL, "tr_conv3x3: bad compute dtype %d", d->compute);
+    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16 || d->compute == TR_F16, TR_EINVAL, "tr_conv3x3: bad compute dtype %d", d->compute);
     TR_REQUIRE(d->in.ptr && d->out.ptr && d->wpacked, TR_EINVAL, "tr_conv3x3: in/out/wpacked must be set");
     TR_REQUIRE(d->in.dtype == d->compute, TR_EUNSUPPORTED, "tr_conv3x3: input dtype %d must equal compute dtype %d",
                d->in.dtype, d->compute);
-    const int eps = d->compute == TR_BF16 ? 8 : 4;
+    const int eps = d->compute == TR_F32 ? 4 : 8;
     TR_REQUIRE(d->cin % eps == 0, TR_EALIGN, "tr_conv3x3: cin=%d must be a multiple of %d (pad the view)", d->cin, eps);
     TR_REQUIRE(view_ok(d->in, d->cin), TR_EINVAL, "tr_conv3x3: input view does not hold cin=%d channels", d->cin);
     TR_REQUIRE(tr::view_vec16B_ok(d->in), TR_EALIGN, "tr_conv3x3: input view is not 16-byte sliceable");
@@ -681,7 +684,7 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     const bool roomy = a.h >= 16 && (int64_t)d->n * ((a.h + 15) / 16) * a.ntx * g.ncg >= 512;
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_conv3x3: ksize must be 3 or 1 (got %d)", d->ksize);
     TR_REQUIRE(d->ksize == 3 || (d->in_mode != TR_IN_NEAREST2X && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct / full / valid input");
-    if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID) {
+    if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID && d->compute != TR_F16) {
         TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
                    "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
         const bool big = force_r ? force_r == 4 : roomy;
@@ -695,32 +698,32 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     }
     // register-staged: 32-wide output groups take 16-row tiles (twice the MFMAs per staged weight slab); 64-wide groups
     // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
-    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : (roomy && !(d->compute == TR_BF16 && d->ksize == 3 && d->cin <= 96)));
-    const bool bf = d->compute == TR_BF16;
+    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : (roomy && !(d->compute != TR_F32 && d->ksize == 3 && d->cin <= 96)));
+    const int ct = d->compute;
+#define TR_BY_CT(FN, ...) (ct == TR_BF16 ? FN<TR_BF16, __VA_ARGS__> : ct == TR_F16 ? FN<TR_F16, __VA_ARGS__> : FN<TR_F32, __VA_ARGS__>)
     static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
     if (d->ksize == 1 && a.w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
         // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
         const int ncgb = g.ncg == 4 ? 2 : (g.ncg < 3 ? g.ncg : 3);
         const int nblk = (g.ncg + ncgb - 1) / ncgb;
         a.nty = (a.h + 3) / 4;
-        if (ncgb == 3) return bf ? launch_linear<TR_BF16, 3>(st, a, nblk) : launch_linear<TR_F32, 3>(st, a, nblk);
-        if (ncgb == 2) return bf ? launch_linear<TR_BF16, 2>(st, a, nblk) : launch_linear<TR_F32, 2>(st, a, nblk);
-        return bf ? launch_linear<TR_BF16, 1>(st, a, nblk) : launch_linear<TR_F32, 1>(st, a, nblk);
+        if (ncgb == 3) return TR_BY_CT(launch_linear, 3)(st, a, nblk);
+        if (ncgb == 2) return TR_BY_CT(launch_linear, 2)(st, a, nblk);
+        return TR_BY_CT(launch_linear, 1)(st, a, nblk);
     }
     if (d->ksize == 1) {
         if (big) {
             a.nty = (a.h + 15) / 16;
-            return bf ? launch_reg<TR_BF16, 1, 4, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 1>(st, a, g.ncg);
+            return TR_BY_CT(launch_reg, 1, 4, 1)(st, a, g.ncg);
         }
         a.nty = (a.h + 7) / 8;
-        if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 1>(st, a, g.ncg);
-        return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 1>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 1>(st, a, g.ncg);
+        return g.cgw == 64 ? TR_BY_CT(launch_reg, 2, 2, 1)(st, a, g.ncg) : TR_BY_CT(launch_reg, 1, 2, 1)(st, a, g.ncg);
     }
     if (big) {
         a.nty = (a.h + 15) / 16;
-        return bf ? launch_reg<TR_BF16, 1, 4, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 4, 3>(st, a, g.ncg);
+        return TR_BY_CT(launch_reg, 1, 4, 3)(st, a, g.ncg);
     }
     a.nty = (a.h + 7) / 8;
-    if (bf) return g.cgw == 64 ? launch_reg<TR_BF16, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_BF16, 1, 2, 3>(st, a, g.ncg);
-    return g.cgw == 64 ? launch_reg<TR_F32, 2, 2, 3>(st, a, g.ncg) : launch_reg<TR_F32, 1, 2, 3>(st, a, g.ncg);
+    return g.cgw == 64 ? TR_BY_CT(launch_reg, 2, 2, 3)(st, a, g.ncg) : TR_BY_CT(launch_reg, 1, 2, 3)(st, a, g.ncg);
+#undef TR_BY_CT
 }

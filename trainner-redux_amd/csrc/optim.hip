@@ -11,7 +11,7 @@
 namespace {
 
 struct Hyper {
-    float lr, b1, b2, eps, wd, bc1, rsqrt_bc2, ema_decay, clip;
+    float lr, b1, b2, eps, wd, bc1, rsqrt_bc2, ema_decay, clip, inv_scale;
 };
 
 __device__ __forceinline__ void upd(float& p, float g, float& m, float& v, const Hyper& h) {
@@ -27,10 +27,10 @@ __device__ __forceinline__ void upd(float& p, float g, float& m, float& v, const
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                      float* __restrict__ v, float* __restrict__ ema, int64_t numel, Hyper h,
                                                      const float* __restrict__ gnorm, int zero_grad) {
-    float gs = 1.f;
+    float gs = h.inv_scale;                            // GradScaler.unscale_ (1 when no loss scaling is in use)
     if (h.clip > 0.f) {
-        const float c = h.clip / (gnorm[0] + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (total + 1e-6), max = 1)
-        gs = c < 1.f ? c : 1.f;
+        const float c = h.clip / (gnorm[0] * h.inv_scale + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (total + 1e-6), max = 1)
+        gs *= c < 1.f ? c : 1.f;
     }
     const float one_minus_decay = 1.f - h.ema_decay;
     const int64_t n4 = numel >> 2;
@@ -69,6 +69,7 @@ extern "C" int tr_adamw_ema(void* stream, const tr_adamw_desc* d) {
     Hyper h;
     h.lr = d->lr; h.b1 = d->beta1; h.b2 = d->beta2; h.eps = d->eps; h.wd = d->weight_decay;
     h.bc1 = d->bias_corr1; h.rsqrt_bc2 = 1.f / sqrtf(d->bias_corr2); h.ema_decay = d->ema_decay; h.clip = d->clip;
+    h.inv_scale = (d->inv_scale == 0.f) ? 1.f : d->inv_scale;
     int64_t b = (d->numel / 4 + 255) / 256;
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const tr_pack_seg* __restrict
         const int row = tp * g.cgw + col;
         const int64_t off = (((int64_t)cg * g.nchunks + chunk) * kk * g.cgw + row) * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
         char* dst = (char*)s.dst + off;
-        if (s.compute == TR_BF16) ((unsigned short*)dst)[e] = tr::f32_to_bf16(val);
+        if (s.compute != TR_F32) ((unsigned short*)dst)[e] = tr::f32_to_h(val, s.compute);
         else ((float*)dst)[e] = val;
     }
 }

@@ -22,6 +22,8 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int TW = 32, TH = 8;
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
     // tile rows and emit their own partial blocks (the reduction kernel sums 3x as many).
     constexpr int PAD = KS / 2;
     constexpr int HALO_W = TW + KS - 1, HALO_H = TH + KS - 1;
-    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int ES = CT == TR_F32 ? 4 : 2;
     constexpr int EPS = 16 / ES;
     constexpr int CG = NT * 32;
     constexpr int XPIX_BYTES = CKW * ES;                 // 64 (bf16) / 128 (f32)
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
     constexpr int GPIX_BYTES = CG * ES;
     constexpr int GSLOTS = GPIX_BYTES / 16;
     constexpr int X_BYTES = HALO_H * HALO_W * XPIX_BYTES;
-    constexpr bool GSWZ = (CT == TR_BF16 && NT == 2);    // 128-byte bf16 rows: swap 64-byte halves on odd pixel pairs
+    constexpr bool GSWZ = (CT != TR_F32 && NT == 2);     // 128-byte 16-bit rows: swap 64-byte halves on odd pixel pairs
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xl = smem;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
         __syncthreads();
         if (tile + a.nslots < a.ntiles) TR_WG_ISSUE(tile + a.nslots)   // in flight during this tile's MFMAs
 
-        if constexpr (CT == TR_BF16) {
+        if constexpr (CT != TR_F32) {
             // Software-pipelined over the 16 (row, 16-pixel half) steps of the tile: the transposing LDS reads of step s+1 are issued
             // before the MFMAs of step s, and every address is ONE lane-constant base plus a compile-time offset (the loop is fully
             // unrolled), so a step costs its MFMAs + 2*(NT+KS) ds_read_b64_tr_b16 and nothing else.  (The rolled version spent its
@@ -192,16 +194,21 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
                 for (int kx = 0; kx < KS; ++kx)
 #pragma unroll
                     for (int t2 = 0; t2 < NT; ++t2)
-                        acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][t2], fb[cur][kx], acc[kx][t2], 0, 0, 0);
+                    {
+                        if constexpr (CT == TR_BF16) acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][t2], fb[cur][kx], acc[kx][t2], 0, 0, 0);
+                        else acc[kx][t2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[cur][t2]), __builtin_bit_cast(f16x8, fb[cur][kx]), acc[kx][t2], 0, 0, 0);
+                    }
                 if (do_bias) {
 #pragma unroll
                     for (int t2 = 0; t2 < NT; ++t2) {
                         const uint4 u = __builtin_bit_cast(uint4, fa[cur][t2]);
                         float sacc = bsum[t2];
-                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.x), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
-                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.y), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
-                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.z), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
-                        sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, u.w), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if constexpr (CT == TR_BF16) sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w4[e]), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                            else sacc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2v, w4[e]), __builtin_bit_cast(f16x2v, 0x3C003C00u), sacc, false);
+                        }
                         bsum[t2] = sacc;
                     }
                 }
@@ -327,7 +334,7 @@ Plan make_plan(int n, int h, int w, int cin, int cout, int ks = 3, int total_wgs
 
 template <int CT, int NT, int KS>
 int launch_wgrad(hipStream_t st, const WgArgs& a) {
-    constexpr int ES = CT == TR_BF16 ? 2 : 4;
+    constexpr int ES = CT == TR_F32 ? 4 : 2;
     constexpr size_t lds = (size_t)(TH + KS - 1) * (TW + KS - 1) * CKW * ES + (size_t)TH * TW * NT * 32 * ES;
     static bool attr_set = false;
     if (!attr_set) {
@@ -354,11 +361,11 @@ extern "C" size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cou
 extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_wgrad3x3: null descriptor");
     TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, TR_EINVAL, "tr_wgrad3x3: bad dims");
-    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16, TR_EINVAL, "tr_wgrad3x3: bad compute dtype");
+    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16 || d->compute == TR_F16, TR_EINVAL, "tr_wgrad3x3: bad compute dtype");
     TR_REQUIRE(d->in.ptr && d->gy.ptr && d->dw && d->partials, TR_EINVAL, "tr_wgrad3x3: in/gy/dw/partials must be set");
     TR_REQUIRE(d->in.dtype == d->compute && d->gy.dtype == d->compute, TR_EUNSUPPORTED,
                "tr_wgrad3x3: operand dtypes must equal the compute dtype");
-    const int eps = d->compute == TR_BF16 ? 8 : 4;
+    const int eps = d->compute == TR_F32 ? 4 : 8;
     TR_REQUIRE(d->in.c % eps == 0 && d->gy.c % eps == 0 && d->in.c >= d->cin && d->gy.c >= d->cout, TR_EALIGN,
                "tr_wgrad3x3: view channel counts must be multiples of %d covering cin/cout", eps);
     TR_REQUIRE(tr::view_vec16B_ok(d->in) && tr::view_vec16B_ok(d->gy), TR_EALIGN, "tr_wgrad3x3: views are not 16-byte sliceable");
@@ -373,7 +380,7 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     // (146 VGPRs), 2 for 64-wide bf16 and 32-wide f32, 1 for 64-wide f32; the workspace query assumes the largest (768)
     static const int wgs_env = getenv("TRAINNER_WGRAD_WGS") ? atoi(getenv("TRAINNER_WGRAD_WGS")) : 0;
     const bool wide = d->cout > 32;
-    const int wgs = wgs_env ? wgs_env : (d->compute == TR_BF16 ? (wide ? 512 : 768) : (wide ? 256 : 512));
+    const int wgs = wgs_env ? wgs_env : (d->compute != TR_F32 ? (wide ? 512 : 768) : (wide ? 256 : 512));
     const Plan p = make_plan(d->n, d->h, d->w, d->cin, d->cout, d->ksize, wgs);
     TR_REQUIRE(d->partials_bytes >= (p.dw_floats + p.db_floats) * sizeof(float), TR_EINVAL,
                "tr_wgrad3x3: workspace too small (%zu < %zu bytes)", d->partials_bytes, (p.dw_floats + p.db_floats) * sizeof(float));
@@ -394,9 +401,11 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     int rc;
     if (d->ksize == 1) {
         if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2, 1>(st, a) : launch_wgrad<TR_BF16, 1, 1>(st, a);
+        else if (d->compute == TR_F16) rc = p.cgw == 64 ? launch_wgrad<TR_F16, 2, 1>(st, a) : launch_wgrad<TR_F16, 1, 1>(st, a);
         else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2, 1>(st, a) : launch_wgrad<TR_F32, 1, 1>(st, a);
     } else {
         if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2, 3>(st, a) : launch_wgrad<TR_BF16, 1, 3>(st, a);
+        else if (d->compute == TR_F16) rc = p.cgw == 64 ? launch_wgrad<TR_F16, 2, 3>(st, a) : launch_wgrad<TR_F16, 1, 3>(st, a);
         else rc = p.cgw == 64 ? launch_wgrad<TR_F32, 2, 3>(st, a) : launch_wgrad<TR_F32, 1, 3>(st, a);
     }
     if (rc) return rc;

@@ -16,6 +16,7 @@ The NaN/Inf check of :665 is evaluated on the host at log time (same RuntimeErro
 """
 from __future__ import annotations
 
+import math
 import os
 from collections import OrderedDict
 from typing import Any
@@ -34,6 +35,36 @@ from .ema import EMA
 ARCHS_WITHOUT_FP16_PREFIXES = ("swinir",)  # arch_info.py:48-50 (all swinir_* are bf16-only)
 
 
+class LossScaler:
+    """torch.amp.GradScaler's schedule (init 65536, x2 after 2000 clean steps, x0.5 on inf/nan) with the scale kept on the host: the
+    scaled loss gradient is produced by the loss heads (grad_weight * scale), `unscale_` is folded into the AdamW sweep, and the
+    inf check is the finiteness of the (already computed) gradient norm -- the reference's scaler.step() syncs on found_inf too."""
+
+    def __init__(self, enabled: bool, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000):
+        self.enabled, self.scale = enabled, float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval, self._growth_tracker = growth_factor, backoff_factor, growth_interval, 0
+
+    def update(self, found_inf: bool) -> None:
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._growth_tracker = 0
+        else:
+            self._growth_tracker += 1
+            if self._growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._growth_tracker = 0
+
+    def state_dict(self) -> dict:
+        return {"scale": self.scale, "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": self._growth_tracker} if self.enabled else {}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if self.enabled and sd:
+            self.scale, self._growth_tracker = float(sd["scale"]), int(sd["_growth_tracker"])
+
+
 class SRModel:
     def __init__(self, opt) -> None:
         self.opt = opt
@@ -43,10 +74,12 @@ class SRModel:
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.use_amp = bool(opt.use_amp)
         self.amp_bf16 = bool(opt.amp_bf16)
-        if self.use_amp and not self.amp_bf16:
-            raise NotImplementedError("fp16 AMP (GradScaler path) is not built yet on the HIP path: set amp_bf16: true")
-        self.compute_dtype = torch.bfloat16 if self.use_amp else torch.float32
+        # use_amp without amp_bf16 = fp16 autocast + GradScaler in the reference (sr_model.py:188-191): fp16 MFMA operands + loss scaling here
+        self.compute_dtype = (torch.bfloat16 if self.amp_bf16 else torch.float16) if self.use_amp else torch.float32
         self.amp_dtype = self.compute_dtype
+        fp16 = self.use_amp and not self.amp_bf16
+        self.scaler_g = LossScaler(enabled=fp16)
+        self.scaler_d = LossScaler(enabled=fp16)
         self.schedulers: list = []
         self.optimizers: list = []
         self.optimizers_skipped: list[bool] = []
@@ -276,6 +309,9 @@ class SRModel:
         acc = self.accum_iters
         skip_d_update = False
         foreign_total = None
+        S = self.scaler_g.scale            # loss scale (1.0 unless fp16): only the GRADIENT weights carry it, logged values do not
+        if self.scaler_g.enabled and not hip_net:
+            raise NotImplementedError("fp16 + loss scaling is built for the HIP generators only; use amp_bf16: true with foreign modules")
 
         for label, loss in self.losses.items():
             w = abs(loss.loss_weight)
@@ -287,7 +323,7 @@ class SRModel:
                 logits = self.net_d.forward_hip(self.output, train=True)
                 g_logits = torch.empty_like(logits)
                 loss.hip_value_and_grad(logits, True, False, value_weight=w, value_out=scal[slot:], total_weight=w / acc, total_out=total,
-                                        grad_weight=w / acc, grad=g_logits)
+                                        grad_weight=w / acc * S, grad=g_logits)
                 self.net_d.backward_hip(g_logits, param_grads=False, input_grad=gout, input_grad_accumulate=not first)
                 keys.append(label)
                 first = False
@@ -296,7 +332,7 @@ class SRModel:
                 is_dict = getattr(loss, "returns_dict", False)
                 k = float(acc) if is_dict else 1.0 / acc
                 subs = loss.hip_value_and_grad(self.output, gt, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
-                                               grad_weight=w * k, grad=gout, first=first)
+                                               grad_weight=w * k * S, grad=gout, first=first)
                 keys += [f"{label}_{sub}" for sub in subs] if subs else [label]
                 first = False
             else:
@@ -319,7 +355,7 @@ class SRModel:
         if foreign_total is not None:
             total += foreign_total.detach().float()
             if hip_net:
-                (g_foreign,) = torch.autograd.grad(foreign_total, out_leaf)
+                (g_foreign,) = torch.autograd.grad(foreign_total * S, out_leaf)
                 if first:
                     gout.copy_(g_foreign)
                 else:
@@ -354,27 +390,40 @@ class SRModel:
                 self._gnorm = scal[GN_G:GN_G + 1]
                 keys.append("grad_norm_g")
                 idx.append(GN_G)
-                ema_arena, ema_decay = None, 1.0
-                if self.net_g_ema is not None:
-                    d = self.net_g_ema.advance()
-                    ema_arena = self.net_g_ema.ema_arena()
-                    if d is None or ema_arena is None:
-                        ema_arena = None
-                        if d is not None:
-                            self._deferred_ema = d
-                    else:
-                        ema_decay = d
-                if isinstance(self.optimizer_g, AdamW):
-                    self.optimizer_g.set_step_extras(ema_arena=ema_arena, ema_decay=ema_decay,
-                                                     clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=self._gnorm)
-                    self.optimizer_g.step()
-                else:
-                    if self.grad_clip:
-                        torch.nn.utils.clip_grad_norm_(net.parameters(), self.grad_clip_threshold)
-                    self.optimizer_g.step()
+                found_inf = False
+                if self.scaler_g.enabled:           # GradScaler.step(): skip the update when the scaled gradients overflowed
+                    found_inf = not math.isfinite(float(self._gnorm))
+                if found_inf:
                     garr.zero_()
-                    if self.net_g_ema is not None and ema_arena is not None:
-                        self.net_g_ema._lerp(ema_decay)
+                    self.optimizers_skipped[0] = True
+                else:
+                    ema_arena, ema_decay = None, 1.0
+                    if self.net_g_ema is not None:
+                        d = self.net_g_ema.advance()
+                        ema_arena = self.net_g_ema.ema_arena()
+                        if d is None or ema_arena is None:
+                            ema_arena = None
+                            if d is not None:
+                                self._deferred_ema = d
+                        else:
+                            ema_decay = d
+                    if isinstance(self.optimizer_g, AdamW):
+                        self.optimizer_g.set_step_extras(ema_arena=ema_arena, ema_decay=ema_decay, inv_scale=1.0 / S,
+                                                         clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=self._gnorm)
+                        self.optimizer_g.step()
+                    else:
+                        if S != 1.0:
+                            garr.mul_(1.0 / S)
+                        if self.grad_clip:
+                            torch.nn.utils.clip_grad_norm_(net.parameters(), self.grad_clip_threshold)
+                        self.optimizer_g.step()
+                        garr.zero_()
+                        if self.net_g_ema is not None and ema_arena is not None:
+                            self.net_g_ema._lerp(ema_decay)
+                    if S != 1.0:
+                        self._gnorm.mul_(1.0 / S)       # logged norm = after unscale_ (sr_model.py:688-705); stream-ordered after the sweep
+                    self.optimizers_skipped[0] = False
+                self.scaler_g.update(found_inf)
             else:
                 if world > 1:
                     for p in net.parameters():
@@ -387,7 +436,7 @@ class SRModel:
                 self.optimizer_g.zero_grad()
                 if self.net_g_ema is not None:
                     self.net_g_ema.update()
-            self.optimizers_skipped[0] = False
+                self.optimizers_skipped[0] = False
 
         # ---- discriminator update (sr_model.py:725-808) ------------------------------------------------------------------
         cri_gan = self.losses.get("l_g_gan")
@@ -398,7 +447,7 @@ class SRModel:
                 for img, is_real, slot_ in ((gt, True, LD_REAL), (self.output, False, LD_FAKE)):
                     logits = dnet.forward_hip(img, train=True)
                     g_logits = torch.empty_like(logits)
-                    cri_gan.hip_value_and_grad(logits, is_real, True, value_weight=1.0, value_out=scal[slot_:], grad_weight=wd / acc,
+                    cri_gan.hip_value_and_grad(logits, is_real, True, value_weight=1.0, value_out=scal[slot_:], grad_weight=wd / acc * self.scaler_d.scale,
                                                grad=g_logits)
                     dnet.backward_hip(g_logits, param_grads=True)
                 keys += ["l_d_real", "l_d_fake"]
@@ -412,14 +461,26 @@ class SRModel:
                     ops.sumsq_norm(garr_d, scal[GN_D:GN_D + 1])
                     keys.append("grad_norm_d")
                     idx.append(GN_D)
-                    if isinstance(self.optimizer_d, AdamW):
-                        self.optimizer_d.set_step_extras(clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=scal[GN_D:GN_D + 1])
+                    Sd = self.scaler_d.scale
+                    found_inf_d = self.scaler_d.enabled and not math.isfinite(float(scal[GN_D]))
+                    if found_inf_d:
+                        garr_d.zero_()
+                    elif isinstance(self.optimizer_d, AdamW):
+                        self.optimizer_d.set_step_extras(clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=scal[GN_D:GN_D + 1],
+                                                         inv_scale=1.0 / Sd)
                         self.optimizer_d.step()
                     else:
+                        if Sd != 1.0:
+                            garr_d.mul_(1.0 / Sd)
                         if self.grad_clip:
                             torch.nn.utils.clip_grad_norm_(dnet.parameters(), self.grad_clip_threshold)
                         self.optimizer_d.step()
                         garr_d.zero_()
+                    if Sd != 1.0 and not found_inf_d:
+                        scal[GN_D:GN_D + 1].mul_(1.0 / Sd)
+                    self.scaler_d.update(found_inf_d)
+                    if len(self.optimizers_skipped) > 1:
+                        self.optimizers_skipped[-1] = found_inf_d
             else:   # stock-PyTorch discriminator from the open plugin surface: ordinary autograd
                 for p in self.net_d.parameters():
                     p.requires_grad = True
@@ -449,7 +510,7 @@ class SRModel:
                         torch.nn.utils.clip_grad_norm_(self.net_d.parameters(), self.grad_clip_threshold)
                     self.optimizer_d.step()
                     self.optimizer_d.zero_grad()
-            if apply_gradient and len(self.optimizers_skipped) > 1:
+            if apply_gradient and len(self.optimizers_skipped) > 1 and not (hasattr(self.net_d, "forward_hip") and hasattr(cri_gan, "hip_value_and_grad")):
                 self.optimizers_skipped[-1] = False
 
         # device-resident log values of this step; read back lazily by get_current_log()
@@ -507,7 +568,7 @@ class SRModel:
 
     def save_training_state(self, epoch: int, current_iter: int) -> None:
         """`{iter}.state` in the reference's layout (base_model.py:713-791): epoch, iter, optimizer and scheduler state dicts (the
-        optimizer's are torch.optim.AdamW-compatible per-parameter entries), EMA step.  No GradScaler entries: bf16 / fp32 only."""
+        optimizer's are torch.optim.AdamW-compatible per-parameter entries), EMA step, scaler_g / scaler_d under fp16."""
         p = self.opt.path
         if p.training_states is None:
             raise ValueError("opt.path.training_states is not set")
@@ -517,6 +578,8 @@ class SRModel:
                  "schedulers": [s.state_dict() for s in self.schedulers]}
         if self.net_g_ema is not None:
             state["ema_step"] = self.net_g_ema.step.detach().cpu().clone()
+        if self.scaler_g.enabled:
+            state["scaler_g"], state["scaler_d"] = self.scaler_g.state_dict(), self.scaler_d.state_dict()
         os.makedirs(p.training_states, exist_ok=True)
         torch.save(state, os.path.join(p.training_states, f"{current_iter}.state"))
 
@@ -529,6 +592,10 @@ class SRModel:
             o.load_state_dict(sd)
         for s, sd in zip(self.schedulers, rs):
             s.load_state_dict(sd)
+        if "scaler_g" in resume_state:
+            self.scaler_g.load_state_dict(resume_state["scaler_g"])
+        if "scaler_d" in resume_state:
+            self.scaler_d.load_state_dict(resume_state["scaler_d"])
         if "ema_step" in resume_state and self.net_g_ema is not None:
             self.net_g_ema.step.copy_(resume_state["ema_step"])
             self.net_g_ema.initted.fill_(True)

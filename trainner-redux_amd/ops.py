@@ -12,18 +12,18 @@ import torch
 
 from . import _lib as L
 
-_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
 
 
 def dt_code(dtype: torch.dtype) -> int:
     try:
         return _DT[dtype]
     except KeyError:
-        raise TypeError(f"unsupported dtype {dtype}; the HIP path handles float32 and bfloat16") from None
+        raise TypeError(f"unsupported dtype {dtype}; the HIP path handles float32, bfloat16 and float16") from None
 
 
 def torch_dtype(code: int) -> torch.dtype:
-    return torch.bfloat16 if code == L.BF16 else torch.float32
+    return torch.bfloat16 if code == L.BF16 else torch.float16 if code == L.F16 else torch.float32
 
 
 def stream_ptr() -> int:
@@ -372,7 +372,7 @@ def sumsq_norm(x: torch.Tensor, out: torch.Tensor):
 
 
 def adamw_ema(p, g, m, v, ema, *, lr, beta1, beta2, eps, weight_decay, step: int, ema_decay: float = 1.0, clip: float = 0.0,
-              grad_norm: torch.Tensor | None = None, zero_grad=True):
+              grad_norm: torch.Tensor | None = None, zero_grad=True, inv_scale: float = 1.0):
     _need_cuda(p, g, m, v, ema)
     d = L.AdamWDesc()
     d.p, d.g, d.m, d.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
@@ -385,4 +385,5 @@ def adamw_ema(p, g, m, v, ema, *, lr, beta1, beta2, eps, weight_decay, step: int
     d.clip = clip
     d.grad_norm = grad_norm.data_ptr() if grad_norm is not None else None
     d.zero_grad = 1 if zero_grad else 0
+    d.inv_scale = inv_scale
     L.check(L.lib().tr_adamw_ema(stream_ptr(), C.byref(d)), "tr_adamw_ema")

@@ -43,6 +43,7 @@ class AdamW(torch.optim.Optimizer):
         self._clip = 0.0
         self._grad_norm = None
         self._grad_scale_world = 1
+        self._inv_scale = 1.0
 
     def load_state_dict(self, state_dict) -> None:
         """torch.optim.AdamW-compatible per-parameter state (`step`, `exp_avg`, `exp_avg_sq`): the loaded tensors are adopted by the
@@ -52,9 +53,10 @@ class AdamW(torch.optim.Optimizer):
 
     # -- fused extras -------------------------------------------------------------------------------
     def set_step_extras(self, *, ema_arena: torch.Tensor | None = None, ema_decay: float = 1.0, clip: float = 0.0,
-                        grad_norm: torch.Tensor | None = None) -> None:
-        """EMA target / decay, clip threshold and the device-resident gradient norm for the NEXT step()."""
-        self._ema_arena, self._ema_decay, self._clip, self._grad_norm = ema_arena, ema_decay, clip, grad_norm
+                        grad_norm: torch.Tensor | None = None, inv_scale: float = 1.0) -> None:
+        """EMA target / decay, clip threshold, the device-resident gradient norm and the loss-scale reciprocal (GradScaler.unscale_
+        folded into the sweep) for the NEXT step()."""
+        self._ema_arena, self._ema_decay, self._clip, self._grad_norm, self._inv_scale = ema_arena, ema_decay, clip, grad_norm, inv_scale
 
     def _group_arenas(self, group):
         """Split a param group into arenas (fused) and loose tensors."""
@@ -105,7 +107,7 @@ class AdamW(torch.optim.Optimizer):
                 ema = self._ema_arena if (self._ema_arena is not None and self._ema_arena.numel() == pa.numel()) else None
                 ops.adamw_ema(pa, ga, st["m"], st["v"], ema, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                               weight_decay=group["weight_decay"], step=st["step"], ema_decay=self._ema_decay, clip=self._clip,
-                              grad_norm=self._grad_norm, zero_grad=True)
+                              grad_norm=self._grad_norm, zero_grad=True, inv_scale=self._inv_scale)
                 for p, _, _ in members:
                     self.state[p]["step"] += 1
             for p in loose:
@@ -117,7 +119,7 @@ class AdamW(torch.optim.Optimizer):
                     raise RuntimeError("fused AdamW needs contiguous parameters and gradients")
                 ops.adamw_ema(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], None, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                               weight_decay=group["weight_decay"], step=int(st["step"]), clip=self._clip, grad_norm=self._grad_norm,
-                              zero_grad=False)
+                              zero_grad=False, inv_scale=self._inv_scale)
         return loss
 
 
