@@ -56,7 +56,7 @@ def read_rgb_u8(path: str) -> np.ndarray:
     from PIL import Image
 
     with Image.open(path) as im:
-        return np.asarray(im.convert("RGB"))
+        return np.array(im.convert("RGB"))       # a writable copy (np.asarray of a PIL image is read-only)
 
 
 def augment_pair(gt: np.ndarray, lq: np.ndarray, hflip: bool, vflip: bool, rot90: bool):
@@ -128,7 +128,7 @@ class PairedImageDataset(data.Dataset):
             gt, lq, _ = paired_random_crop(gt, lq, get("gt_size"), scale, p["gt_path"])
         else:
             gt = gt[0:lq.shape[0] * scale, 0:lq.shape[1] * scale]
-        gt_t, lq_t = torch.from_numpy(np.ascontiguousarray(gt)), torch.from_numpy(np.ascontiguousarray(lq))
+        gt_t, lq_t = torch.from_numpy(np.ascontiguousarray(gt).copy()), torch.from_numpy(np.ascontiguousarray(lq).copy())
         if not self.as_uint8:
             gt_t = gt_t.permute(2, 0, 1).float().div_(255.0)
             lq_t = lq_t.permute(2, 0, 1).float().div_(255.0)
