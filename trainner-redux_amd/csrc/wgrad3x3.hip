@@ -16,6 +16,7 @@
 //     bitwise reproducible, no float atomics.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -306,6 +307,171 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+
+// ---- nn.Linear weight gradient (ksize 1, direct input) as a split-K GEMM ----------------------------------------------------------
+// dW[co][ci] = sum_t gy[t][co] x[t][ci]: M = cout, N = cin, K = tokens.  The 3x3 kernel's tiling (one 32-channel input chunk x one
+// 64-channel output group per workgroup) has no tap reuse to amortise its loads at ksize 1 (measured 110 TFLOP/s on SwinIR-M's qkv).
+// Here a workgroup owns a 128 (cout) x 192 (cin) block -- 2 x 2 waves, 64 x 96 each = 2 x 3 MFMA tiles -- and walks its share of the
+// tokens 32 at a time: both operands are K-major in memory, so both MFMA fragments come out of row-major LDS tiles through
+// ds_read_b64_tr_b16; next step's 20 KB are prefetched into registers.  Partial blocks go out in the 3x3 kernel's layout, so the same
+// deterministic second-stage reduction applies.
+struct LwArgs {
+    tr_view in, gy;
+    float* partials;
+    float* db_partials;
+    int64_t ntok;
+    int cin, cout, nchunks, ncg, nslots, nsteps;
+};
+constexpr int LW_TOK = 32, LW_CO = 128, LW_CI = 192;
+constexpr int LW_GROW = LW_CO * 2 + 16, LW_XROW = LW_CI * 2 + 16;   // padded LDS rows (bytes): 4 consecutive rows hit different banks
+
+struct LwPlan { int ncg, nchunks, ncb, nib, nsteps, nslots; size_t dw_floats, db_floats; };
+LwPlan lw_plan(int64_t ntok, int cin, int cout) {
+    LwPlan p;
+    p.ncg = (cout + 63) / 64;
+    p.nchunks = (cin + CKW - 1) / CKW;
+    p.ncb = (p.ncg + 1) / 2;
+    p.nib = (p.nchunks + 5) / 6;
+    p.nsteps = (int)((ntok + LW_TOK - 1) / LW_TOK);
+    int target = 512 / (p.ncb * p.nib);
+    if (target < 1) target = 1;
+    // every slot writes a full cout x cin partial block: keep >= LW_MIN_STEPS token steps per slot so that the partial traffic stays
+    // well below the operand traffic (at 32k tokens 102 slots wrote 45 MB of partials against 48 MB of operands)
+    static const int min_steps = getenv("TRAINNER_LW_MINSTEPS") ? atoi(getenv("TRAINNER_LW_MINSTEPS")) : 16;
+    const int cap = p.nsteps / min_steps > 0 ? p.nsteps / min_steps : 1;
+    if (target > cap) target = cap;
+    p.nslots = p.nsteps < target ? p.nsteps : target;
+    p.dw_floats = (size_t)p.nslots * p.nchunks * p.ncg * 64 * CKW;
+    p.db_floats = (size_t)p.nslots * p.ncg * 64;
+    return p;
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void wgrad_linear_kernel(LwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* gl = smem;                              // [32 tokens][LW_GROW]
+    char* xl = smem + LW_TOK * LW_GROW;           // [32 tokens][LW_XROW]
+    const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6, lh = l >> 5, lr = l & 31;
+    const int wm = wv >> 1, wn = wv & 1;          // cout half (64), cin half (96)
+    const int slot = blockIdx.x, ib = blockIdx.y, cb = blockIdx.z;
+    const int co0 = cb * LW_CO, ci0 = ib * LW_CI;
+    const unsigned short* gy = (const unsigned short*)a.gy.ptr + a.gy.coff;
+    const unsigned short* xin = (const unsigned short*)a.in.ptr + a.in.coff;
+    const int64_t gcs = a.gy.cstride, xcs = a.in.cstride;
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    const bool do_bias = a.db_partials != nullptr && ib == 0 && wn == 0;
+
+    // staging: 16-byte pieces; G tile 32 x 16 pieces (2 per thread), X tile 32 x 24 pieces (3 per thread)
+    uint4 greg[2], xreg[3];
+#define TR_LW_ISSUE(STEP)                                                                                               \
+    {                                                                                                                   \
+        const int64_t t0 = (int64_t)(STEP) * LW_TOK;                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            const int it = tid + j * 256, tk = it >> 4, pc = it & 15;                                                    \
+            const int c = co0 + pc * 8;                                                                                  \
+            greg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (t0 + tk < a.ntok && c + 8 <= a.gy.c) greg[j] = *(const uint4*)(gy + (t0 + tk) * gcs + c);                \
+        }                                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                                                  \
+            const int it = tid + j * 256, tk = it / 24, pc = it - tk * 24;                                               \
+            const int c = ci0 + pc * 8;                                                                                  \
+            xreg[j] = make_uint4(0, 0, 0, 0);                                                                            \
+            if (t0 + tk < a.ntok && c + 8 <= a.in.c) xreg[j] = *(const uint4*)(xin + (t0 + tk) * xcs + c);               \
+        }                                                                                                               \
+    }
+    // transposing fragment reads: lane -> (row q of 4, 8-byte column group p) inside a 16-lane group; result: 4 tokens for column l & 31
+    const int li = l & 15, q = li >> 2, p4 = li & 3, i0 = ((l >> 4) & 1) * 16;
+    const char* gb = gl + (8 * lh + q) * LW_GROW + (wm * 64 + i0 + 4 * p4) * 2;
+    const char* xb = xl + (8 * lh + q) * LW_XROW + (wn * 96 + i0 + 4 * p4) * 2;
+#define TR_TRRD(PTR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(PTR))
+
+    int step = slot;
+    if (step < a.nsteps) TR_LW_ISSUE(step)
+    for (; step < a.nsteps; step += a.nslots) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int it = tid + j * 256, tk = it >> 4, pc = it & 15;
+            *(uint4*)(gl + tk * LW_GROW + pc * 16) = greg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int it = tid + j * 256, tk = it / 24, pc = it - tk * 24;
+            *(uint4*)(xl + tk * LW_XROW + pc * 16) = xreg[j];
+        }
+        __syncthreads();
+        if (step + a.nslots < a.nsteps) TR_LW_ISSUE(step + a.nslots)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {              // two 16-token MFMA steps
+            bf16x8 fa[2], fb[3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4 lo = TR_TRRD(gb + (kb * 16) * LW_GROW + i * 64), hi = TR_TRRD(gb + (kb * 16 + 4) * LW_GROW + i * 64);
+                fa[i] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const s16x4 lo = TR_TRRD(xb + (kb * 16) * LW_XROW + j * 64), hi = TR_TRRD(xb + (kb * 16 + 4) * LW_XROW + j * 64);
+                fb[j] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    if constexpr (CT == TR_BF16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i]), __builtin_bit_cast(f16x8, fb[j]), acc[i][j], 0, 0, 0);
+                }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint4 u = __builtin_bit_cast(uint4, fa[i]);
+                    const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+                    float sacc = bsum[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (CT == TR_BF16) sacc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, w4[e]), __builtin_bit_cast(bf16x2v, 0x3F803F80u), sacc, false);
+                        else sacc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2v, w4[e]), __builtin_bit_cast(f16x2v, 0x3C003C00u), sacc, false);
+                    }
+                    bsum[i] = sacc;
+                }
+            }
+        }
+    }
+#undef TR_LW_ISSUE
+#undef TR_TRRD
+    const int cg = cb * 2 + wm;
+    if (cg < a.ncg) {
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float v = bsum[i] + __shfl_xor(bsum[i], 32, 64);   // the lane halves hold disjoint tokens of one channel
+                if (lh == 0) a.db_partials[((int64_t)slot * a.ncg + cg) * 64 + i * 32 + lr] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int chunk = ib * 6 + wn * 3 + j;
+            if (chunk >= a.nchunks) continue;
+            float* dst = a.partials + (((int64_t)slot * a.nchunks + chunk) * a.ncg + cg) * (64 * CKW);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int co = i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    dst[co * CKW + lr] = acc[i][j][reg];
+                }
+        }
+    }
+}
+
 struct Plan {
     int ntx, nty, ntiles, nslots, nchunks, ncg, cgw;
     size_t dw_floats, db_floats;
@@ -355,7 +521,12 @@ extern "C" size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int 
 extern "C" size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const Plan p = make_plan(n, h, w, cin, cout, ksize);
-    return (p.dw_floats + p.db_floats) * sizeof(float);
+    size_t fl = p.dw_floats + p.db_floats;
+    if (ksize == 1 && cout > 32) {     // the split-K GEMM path (16-bit compute, direct input) keeps 128 x 192 blocks per workgroup
+        const LwPlan q = lw_plan((int64_t)n * h * w, cin, cout);
+        if (q.dw_floats + q.db_floats > fl) fl = q.dw_floats + q.db_floats;
+    }
+    return fl * sizeof(float);
 }
 
 extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
@@ -376,6 +547,29 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     TR_REQUIRE(d->in_mode < TR_IN_FULL || d->pad_mode == TR_PAD_ZEROS, TR_EINVAL, "tr_wgrad3x3: full / valid modes take zero padding");
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_wgrad3x3: ksize must be 3 or 1");
     TR_REQUIRE(d->dw_ld == 0 || d->dw_ld >= d->cin, TR_EINVAL, "tr_wgrad3x3: dw_ld must be 0 or >= cin");
+    static const bool no_lw = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
+    if (d->ksize == 1 && d->in_mode == TR_IN_DIRECT && d->compute != TR_F32 && d->cout > 32 && !no_lw) {
+        const LwPlan q = lw_plan((int64_t)d->n * d->h * d->w, d->cin, d->cout);
+        TR_REQUIRE(d->partials_bytes >= (q.dw_floats + q.db_floats) * sizeof(float), TR_EINVAL, "tr_wgrad3x3: workspace too small (%zu < %zu bytes)",
+                   d->partials_bytes, (q.dw_floats + q.db_floats) * sizeof(float));
+        LwArgs la;
+        la.in = d->in; la.gy = d->gy; la.partials = d->partials; la.db_partials = d->db ? d->partials + q.dw_floats : nullptr;
+        la.ntok = (int64_t)d->n * d->h * d->w; la.cin = d->cin; la.cout = d->cout; la.nchunks = q.nchunks; la.ncg = q.ncg; la.nslots = q.nslots;
+        la.nsteps = q.nsteps;
+        const size_t lds = (size_t)LW_TOK * (LW_GROW + LW_XROW);
+        hipStream_t st = (hipStream_t)stream;
+        if (d->compute == TR_BF16) hipLaunchKernelGGL(wgrad_linear_kernel<TR_BF16>, dim3(q.nslots, q.nib, q.ncb), dim3(256), lds, st, la);
+        else hipLaunchKernelGGL(wgrad_linear_kernel<TR_F16>, dim3(q.nslots, q.nib, q.ncb), dim3(256), lds, st, la);
+        int rc = tr::launch_status("tr_wgrad3x3(linear)");
+        if (rc) return rc;
+        const int64_t total = (int64_t)d->cout * d->cin;
+        int64_t b = (total + 255) / 256;
+        if (b > 2048) b = 2048;
+        const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, q.nslots, q.nchunks,
+                           q.ncg, 64, d->accumulate, 1, (int)b, d->partials + q.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
+        return tr::launch_status("tr_wgrad3x3(linear reduce)");
+    }
     // one round of RESIDENT workgroups (more would run as a half-empty second round): 3 per CU for the 32-wide bf16 variant
     // (146 VGPRs), 2 for 64-wide bf16 and 32-wide f32, 1 for 64-wide f32; the workspace query assumes the largest (768)
     static const int wgs_env = getenv("TRAINNER_WGRAD_WGS") ? atoi(getenv("TRAINNER_WGRAD_WGS")) : 0;
