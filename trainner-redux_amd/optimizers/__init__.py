@@ -90,26 +90,27 @@ class AdamW(torch.optim.Optimizer):
                     loose.extend(p for p, _, _ in members)  # a partial arena: fall back to per-tensor launches
                     continue
                 if st is None:
-                    st = dict(step=0, m=torch.zeros_like(pa), v=torch.zeros_like(pa))
+                    # ONE step tensor shared by every parameter of the arena (state_dict() still reports it per parameter): bumping a
+                    # tensor per parameter per step cost ~470 tiny ops on SwinIR-M
+                    st = dict(step=0, m=torch.zeros_like(pa), v=torch.zeros_like(pa), step_t=torch.tensor(0.0))
                     self._flat[key] = st
                     for p, _, _ in members:  # expose views so state_dict()/load_state_dict() see per-parameter state
                         off = p.data.storage_offset()
                         old = self.state.get(p) or {}
-                        views = dict(step=torch.tensor(0.0), exp_avg=st["m"][off:off + p.numel()].view(p.shape),
+                        views = dict(step=st["step_t"], exp_avg=st["m"][off:off + p.numel()].view(p.shape),
                                      exp_avg_sq=st["v"][off:off + p.numel()].view(p.shape))
                         if "exp_avg" in old:   # restored by load_state_dict() (resume_training, base_model.py:794-814): move it into the arenas
                             views["exp_avg"].copy_(old["exp_avg"])
                             views["exp_avg_sq"].copy_(old["exp_avg_sq"])
-                            views["step"] = torch.tensor(float(old["step"]))
                             st["step"] = int(float(old["step"]))
+                            st["step_t"].fill_(float(old["step"]))
                         self.state[p] = views
                 st["step"] += 1
                 ema = self._ema_arena if (self._ema_arena is not None and self._ema_arena.numel() == pa.numel()) else None
                 ops.adamw_ema(pa, ga, st["m"], st["v"], ema, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                               weight_decay=group["weight_decay"], step=st["step"], ema_decay=self._ema_decay, clip=self._clip,
                               grad_norm=self._grad_norm, zero_grad=True, inv_scale=self._inv_scale)
-                for p, _, _ in members:
-                    self.state[p]["step"] += 1
+                st["step_t"] += 1
             for p in loose:
                 st = self.state[p]
                 if not st:
