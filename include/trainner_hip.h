@@ -330,6 +330,19 @@ int tr_span_gate_bwd(void* stream, tr_view g, tr_view o3, tr_view x, tr_view g_o
  * paired_image_dataset.py:133-146) -> fp32 NCHW in [0,1], optionally (x/255 - mean[c]) / std[c] (torchvision normalize, :141-143) */
 int tr_u8hwc_to_nchw(void* stream, const uint8_t* src, int n, int h, int w, int c, float* dst, const float* mean3, const float* std3);
 
+/* ---- validation: metrics and tiled-inference blending (sr_model.py:830-899,960-1139; metrics/psnr_ssim.py) --------------------------
+ * tr_metric_prepare: fp32 CHW image in [0,1] -> 8-bit levels (clamp, x255, round: tensor2img), border crop, optional BT.601 luma
+ *                    (metric_util.py:34-47); planes = c' x (h-2crop) x (w-2crop) floats, c' = 1 with y_channel on 3-channel input.
+ * tr_metric_sqerr / tr_metric_ssim: double-precision per-block partial sums (host adds them in order): sum (a-b)^2, and the sum of the
+ *                    SSIM map (11x11 Gaussian window `gauss11`, valid region) over all channels.
+ * tr_tile_blend / tr_tile_normalize: infer_tiled's triangular-weight accumulation and the final division. */
+int tr_metric_prepare(void* stream, const float* img_chw, int c, int h, int w, int crop, int y_channel, float* planes);
+int tr_metric_sqerr(void* stream, const float* a, const float* b, int64_t n, double* partials, int* n_partials);
+int tr_metric_ssim(void* stream, const float* a, const float* b, int nc, int h, int w, const double* gauss11_host, double* partials, int* n_partials);
+int tr_tile_blend(void* stream, const float* patch, int c, int patch_h, int patch_w, float* out, float* wmap, int out_h, int out_w, int y0, int x0,
+                  int ph, int pw, int hr_tile);
+int tr_tile_normalize(void* stream, const float* acc, const float* wmap, int c, int acc_h, int acc_w, float* out, int out_h, int out_w);
+
 #ifdef __cplusplus
 }
 #endif

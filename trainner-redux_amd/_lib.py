@@ -125,6 +125,11 @@ SYMBOLS = {
     "tr_pixel_shuffle": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_axpby": (C.c_int, [C.c_void_p, View, C.c_float, View, C.c_float, View, C.c_int64, View, C.c_float, C.c_void_p, C.c_int64]),
     "tr_u8hwc_to_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "tr_metric_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tr_metric_sqerr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int)]),
+    "tr_metric_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]),
+    "tr_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_tile_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
     "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),

@@ -90,6 +90,7 @@ class SRModel:
         self.output: Tensor | None = None
         self.with_metrics = False
         self.metric_results: dict = {}
+        self.best_metric_results: dict = {}
         self.training_automation_manager = None
         self.batch_augment = None
         self.dynamic_loss_scheduler = None
@@ -521,10 +522,110 @@ class SRModel:
     # ------------------------------------------------------------------ inference / io -----------------------------
     @torch.no_grad()
     def test(self) -> None:
+        """sr_model.py:902-945: EMA net if present, whole image or `val.tile_size` tiles."""
         net = self.net_g_ema.ema_model if self.net_g_ema is not None else self.net_g
         assert self.lq is not None
         lq = self.lq.float()
-        self.output = net.forward_hip(lq, train=False) if hasattr(net, "forward_hip") else net(lq)
+        val = self.opt.val
+        if val is not None and (val.tile_size or 0) > 0:
+            self.output = self.infer_tiled(net, lq)
+        else:
+            self.output = net.forward_hip(lq, train=False) if hasattr(net, "forward_hip") else net(lq)
+
+    @torch.no_grad()
+    def infer_tiled(self, net: nn.Module, lq: Tensor) -> Tensor:
+        """sr_model.py:830-900: reflect-pad to a tile multiple, run `tile_size` tiles with `tile_overlap`, blend with triangular weights
+        (`tr_tile_blend`), divide by the weight map (`tr_tile_normalize`).  Tile geometry and edge handling as in the reference."""
+        import ctypes as C
+
+        from .. import _lib as L
+
+        tile, overlap, scale = self.opt.val.tile_size, self.opt.val.tile_overlap or 0, self.opt.scale
+        fwd = (lambda t: net.forward_hip(t.contiguous(), train=False)) if hasattr(net, "forward_hip") else net
+        b, c, h, w = lq.shape
+        assert b == 1, "Only batch size 1 is supported for tiled inference"
+        if h <= tile and w <= tile:
+            return fwd(lq)
+        pad_h = (tile - (h % tile)) % tile if h > tile else 0
+        pad_w = (tile - (w % tile)) % tile if w > tile else 0
+        lq = torch.nn.functional.pad(lq, (0, pad_w, 0, pad_h), mode="reflect")
+        _, _, hp, wp = lq.shape
+        acc = torch.zeros(c, hp * scale, wp * scale, device=lq.device)
+        wmap = torch.zeros_like(acc)
+        stride = tile - overlap
+        tiles_y = max(1, (hp - overlap + stride - 1) // stride)
+        tiles_x = max(1, (wp - overlap + stride - 1) // stride)
+        lib, st = L.lib(), ops.stream_ptr
+        for y in range(tiles_y):
+            for x in range(tiles_x):
+                y0, x0 = y * stride, x * stride
+                patch = lq[:, :, y0:min(y0 + tile, hp), x0:min(x0 + tile, wp)]
+                ph, pw = patch.shape[-2:]
+                pb = max(tile - ph, 0) if ph < tile else 0
+                pr = max(tile - pw, 0) if pw < tile else 0
+                if pb > 0 or pr > 0:
+                    patch = torch.nn.functional.pad(patch, (0, min(pr, pw - 1), 0, min(pb, ph - 1)), mode="reflect")
+                out = fwd(patch).contiguous()
+                L.check(lib.tr_tile_blend(st(), out.data_ptr(), c, out.shape[2], out.shape[3], acc.data_ptr(), wmap.data_ptr(), hp * scale, wp * scale,
+                                          y0 * scale, x0 * scale, ph * scale, pw * scale, tile * scale), "tr_tile_blend")
+        res = torch.empty(1, c, h * scale, w * scale, device=lq.device)
+        L.check(lib.tr_tile_normalize(st(), acc.data_ptr(), wmap.data_ptr(), c, hp * scale, wp * scale, res.data_ptr(), h * scale, w * scale), "tr_tile_normalize")
+        return res
+
+    def validation(self, dataloader, current_iter: int, tb_logger=None, save_img: bool = False, multi_val_datasets: bool = False) -> None:
+        """base_model.py `validation`: rank 0 validates (dist_validation, sr_model.py:947-958)."""
+        rank, _ = get_dist_info()
+        if rank == 0:
+            self.nondist_validation(dataloader, current_iter, tb_logger, save_img, multi_val_datasets)
+
+    def nondist_validation(self, dataloader, current_iter: int, tb_logger=None, save_img: bool = False, multi_val_datasets: bool = False) -> None:
+        """sr_model.py:960-1139 without the image dump: per validation pair feed_data -> test -> the `val.metrics` on the device;
+        means over the loader in `metric_results`, running best per dataset in `best_metric_results`."""
+        from ..metrics import calculate_metric
+
+        val = self.opt.val
+        assert val is not None
+        ds = dataloader.dataset
+        name = (ds.opt.get("name") if isinstance(getattr(ds, "opt", None), dict) else getattr(getattr(ds, "opt", None), "name", None)) or "val"
+        with_metrics = bool(val.metrics_enabled) and val.metrics is not None
+        if save_img:
+            raise NotImplementedError("validation image dumps are not built; metrics only")
+        if with_metrics:
+            if not self.metric_results:
+                self.metric_results = dict.fromkeys(val.metrics.keys(), 0)
+            self._initialize_best_metric_results(name)
+            self.metric_results = dict.fromkeys(self.metric_results, 0)
+        n = 0
+        for data in dataloader:
+            self.feed_data(data)
+            self.test()
+            n += 1
+            if with_metrics:
+                for key, mopt in val.metrics.items():
+                    self.metric_results[key] += calculate_metric({"img": self.output, "img2": self.gt}, mopt)
+        if with_metrics and n:
+            for key in self.metric_results:
+                self.metric_results[key] /= n
+                self._update_best_metric_result(name, key, self.metric_results[key], current_iter)
+            if tb_logger is not None:
+                for key, v in self.metric_results.items():
+                    tb_logger.add_scalar(f"metrics/{name}/{key}", v, current_iter)
+
+    def _initialize_best_metric_results(self, dataset_name: str) -> None:
+        """base_model.py:160-173"""
+        if dataset_name in self.best_metric_results:
+            return
+        rec = {}
+        for metric, content in self.opt.val.metrics.items():
+            better = content.get("better", "higher")
+            rec[metric] = {"better": better, "val": float("-inf") if better == "higher" else float("inf"), "iter": -1}
+        self.best_metric_results[dataset_name] = rec
+
+    def _update_best_metric_result(self, dataset_name: str, metric: str, val: float, current_iter: int) -> None:
+        """base_model.py:175-184"""
+        r = self.best_metric_results[dataset_name][metric]
+        if (r["better"] == "higher" and val >= r["val"]) or (r["better"] != "higher" and val <= r["val"]):
+            r["val"], r["iter"] = val, current_iter
 
     def load_network(self, net: nn.Module, load_path: str, strict: bool = True, param_key: str | None = None) -> None:
         """safetensors / .pth state dicts (base_model.py:570-648); `param_key` falls back params_ema -> params -> flat."""
