@@ -129,6 +129,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
     const int lr = l & 31, lh = l >> 5;
     char* strip = smem + (strip_id < 0 ? wv : strip_id) * (32 * ROWB);   // wv: row group of the tile; strip_id: wave (when they differ)
     const bool generic = !(a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_res2 && a.vec_mask);
+    // a lane keeps the same 4-channel segment across the iterations of a row when 64 % SEGS == 0: its bias is loaded once per tile
+    // (it used to be four dependent global loads inside every iteration of a rolled loop)
+    constexpr bool FIXED_SEG = (64 % SEGS) == 0;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FIXED_SEG && a.bias) {
+        const int co_ = cg * CGW + (l % SEGS) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (co_ + k < a.cout) bias4[k] = a.bias[co_ + k];
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int oy = y0 + wv * R + r;
@@ -143,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // a rolled loop on purpose: the body (erf GELU, derivative mask, generic tails) is large, and unrolling it ITER x R times
         // pushes the kernel past the unroll budget -- the r loop then stays rolled and `acc` is demoted to scratch memory
-#pragma unroll 1
+#pragma unroll 2
         for (int i = 0; i < ITER; ++i) {
             const int idx = i * 64 + l;
             const int p = idx / SEGS, seg = idx - p * SEGS;
@@ -154,7 +164,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
             float v[4] = {raw.x, raw.y, raw.z, raw.w};
             const bool full = (co + 3) < a.cout;
-            if (a.bias) {
+            if (FIXED_SEG) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += bias4[k];
+            } else if (a.bias) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (co + k < a.cout) v[k] += a.bias[co + k];
@@ -232,7 +245,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // already in flight into registers, so neither the first-load latency of a tile nor its epilogue stores are exposed.
 // One LDS stage; two workgroups per CU cover each other's LDS write phases.
 template <int CT, int NT, int R, int KS>
-__global__ __launch_bounds__(NTHREADS, 2) void conv3x3_kernel_reg(ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && CT != TR_F32) ? 3 : 2) void conv3x3_kernel_reg(ConvArgs a) {
     constexpr int TH = 4 * R;
     constexpr int PAD = KS / 2;                        // KS = 3: 3x3 pad 1 ; KS = 1: 1x1 (token GEMMs: Linear layers)
     constexpr int HALO_W = TW + KS - 1;
