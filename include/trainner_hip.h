@@ -343,6 +343,13 @@ int tr_tile_blend(void* stream, const float* patch, int c, int patch_h, int patc
                   int ph, int pw, int hr_tile);
 int tr_tile_normalize(void* stream, const float* acc, const float* wmap, int c, int acc_h, int acc_w, float* out, int out_h, int out_w);
 
+/* ---- OTF degradation primitives (first slice of SURVEY.md 8f-1) ------------------------------------------------------------------
+ * tr_filter2d: utils/img_process_util.py:8-32 -- reflect pad k/2, cross-correlation of every channel of sample b with kernels[b]
+ *              (per_sample != 0: kernels is n x k x k) or with the single kernel (per_sample == 0); fp32 NCHW in / out; even k is an error.
+ * tr_quantize_u8: models/realesrgan_model.py:621 -- clamp(round(x * 255), 0, 255) / 255. */
+int tr_filter2d(void* stream, const float* img_nchw, const float* kernels, int per_sample, int n, int c, int h, int w, int k, float* out_nchw);
+int tr_quantize_u8(void* stream, const float* x, float* y, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

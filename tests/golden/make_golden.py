@@ -12,6 +12,8 @@ Fixtures
   sampler.pt            data_sampler.EnlargedSampler index streams (epoch-seeded permutation, rank stride)
   unet_discriminator_sn.pt  discriminator_arch.UNetDiscriminatorSN(num_feat=16): weights/u/v before and after one training-mode
                         forward, output, input- and parameter-gradients, eval-mode output
+  filter2d.pt           img_process_util.filter2d (cv2 is only imported by that module, not used by the function): a shared 5x5 kernel and
+                        per-sample 21x21 kernels on small images
   span.pt               span_arch.SPAN (feature_channels 8 / x2 / no norm, and 12 / x4 / norm): state dict, training-mode output (the
                         1x1 -> 3x3 -> 1x1 + skip form of Conv3XC), parameter gradients for a fixed cotangent, eval-mode output (merged
                         3x3) and the merged eval_conv weights.  `spandrel.util.store_hyperparameters` (absent wheel) is a no-op decorator here.
@@ -169,6 +171,18 @@ def main():
         e["state_eval"] = {k: v.clone() for k, v in net.state_dict().items() if "eval_conv" in k}
         fix[tag] = e
     torch.save(fix, os.path.join(OUT, "span.pt"))
+
+    # ---- filter2d (the module imports cv2 / numpy at the top; the function itself is pure torch)
+    _stub("cv2")
+    ipu = _load("traiNNer.utils.img_process_util", "traiNNer/utils/img_process_util.py")
+    g = torch.Generator().manual_seed(5)
+    fix = {}
+    for tag, (b, c, h, w, k, shared) in {"shared5": (2, 3, 17, 23, 5, True), "per_sample21": (3, 3, 40, 36, 21, False), "single7": (1, 1, 9, 12, 7, True)}.items():
+        img = torch.rand(b, c, h, w, generator=g)
+        ker = torch.rand(1 if shared else b, k, k, generator=g)
+        ker = ker / ker.sum(dim=(1, 2), keepdim=True)
+        fix[tag] = {"img": img, "kernel": ker, "out": ipu.filter2d(img, ker)}
+    torch.save(fix, os.path.join(OUT, "filter2d.pt"))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".pt")))
 
 

@@ -130,6 +130,8 @@ SYMBOLS = {
     "tr_metric_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_int)]),
     "tr_tile_blend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_tile_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    "tr_filter2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tr_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
     "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),

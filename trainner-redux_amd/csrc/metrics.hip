@@ -104,6 +104,43 @@ __global__ __launch_bounds__(256) void tile_normalize_kernel(const float* __rest
     }
 }
 
+
+// ---- OTF degradation primitives (first slice): per-sample blur and the 8-bit clamp/round -----------------------------
+//   filter2d              traiNNer/utils/img_process_util.py:8-32  (reflect pad k/2, cross-correlation, one k x k kernel per SAMPLE
+//                         shared by its channels -- or one kernel for the whole batch)
+//   clamp / round         traiNNer/models/realesrgan_model.py:621  torch.clamp((out * 255.0).round(), 0, 255) / 255.0
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void filter2d_kernel(const float* __restrict__ img, const float* __restrict__ kern, int per_sample, int c, int h, int w,
+                                                        int k, float* __restrict__ out) {
+    extern __shared__ float kw[];                        // this sample's k x k weights
+    const int nb = blockIdx.z, ch = blockIdx.y;
+    const float* kp = kern + (per_sample ? (int64_t)nb * k * k : 0);
+    for (int i = threadIdx.x; i < k * k; i += blockDim.x) kw[i] = kp[i];
+    __syncthreads();
+    const float* src = img + ((int64_t)nb * c + ch) * h * w;
+    float* dst = out + ((int64_t)nb * c + ch) * h * w;
+    const int r = k / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)h * w; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / w), x = (int)(i % w);
+        float acc = 0.f;
+        for (int dy = 0; dy < k; ++dy) {
+            const float* row = src + (int64_t)reflect_idx(y + dy - r, h) * w;
+            const float* kr = kw + dy * k;
+            if (x - r >= 0 && x + r < w) {
+                for (int dx = 0; dx < k; ++dx) acc += row[x + dx - r] * kr[dx];
+            } else {
+                for (int dx = 0; dx < k; ++dx) acc += row[reflect_idx(x + dx - r, w)] * kr[dx];
+            }
+        }
+        dst[i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = fminf(fmaxf(rintf(x[i] * 255.0f), 0.f), 255.f) / 255.0f;
+}
+
 unsigned nblocks(int64_t n) {
     int64_t b = (n + 255) / 256;
     return (unsigned)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
@@ -146,4 +183,20 @@ extern "C" int tr_tile_normalize(void* stream, const float* acc, const float* wm
     hipLaunchKernelGGL(tile_normalize_kernel, dim3(nblocks((int64_t)c * out_h * out_w)), dim3(256), 0, (hipStream_t)stream, acc, wmap, c, acc_h, acc_w, out, out_h,
                        out_w);
     return tr::launch_status("tr_tile_normalize");
+}
+
+extern "C" int tr_filter2d(void* stream, const float* img_nchw, const float* kernels, int per_sample, int n, int c, int h, int w, int k, float* out_nchw) {
+    TR_REQUIRE(img_nchw && kernels && out_nchw && n > 0 && c > 0 && h > 0 && w > 0, TR_EINVAL, "tr_filter2d: bad arguments");
+    TR_REQUIRE(k % 2 == 1, TR_EINVAL, "tr_filter2d: Wrong kernel size");           // the reference raises ValueError("Wrong kernel size")
+    TR_REQUIRE(k / 2 < h && k / 2 < w && k <= 63, TR_EUNSUPPORTED, "tr_filter2d: reflect padding needs k/2 < H, W (k <= 63)");
+    unsigned gx = nblocks((int64_t)h * w);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(filter2d_kernel, dim3(gx, c, n), dim3(256), (size_t)k * k * sizeof(float), (hipStream_t)stream, img_nchw, kernels, per_sample, c, h, w,
+                       k, out_nchw);
+    return tr::launch_status("tr_filter2d");
+}
+extern "C" int tr_quantize_u8(void* stream, const float* x, float* y, int64_t n) {
+    TR_REQUIRE(x && y && n > 0, TR_EINVAL, "tr_quantize_u8: bad arguments");
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3(nblocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return tr::launch_status("tr_quantize_u8");
 }
