@@ -536,8 +536,6 @@ class SRModel:
     def infer_tiled(self, net: nn.Module, lq: Tensor) -> Tensor:
         """sr_model.py:830-900: reflect-pad to a tile multiple, run `tile_size` tiles with `tile_overlap`, blend with triangular weights
         (`tr_tile_blend`), divide by the weight map (`tr_tile_normalize`).  Tile geometry and edge handling as in the reference."""
-        import ctypes as C
-
         from .. import _lib as L
 
         tile, overlap, scale = self.opt.val.tile_size, self.opt.val.tile_overlap or 0, self.opt.scale
