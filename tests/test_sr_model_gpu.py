@@ -236,3 +236,29 @@ def test_checkpoint_resume_is_bit_exact(cuda, tmp_path):
         assert torch.equal(va, vb), k
     for va, vb in zip(a.net_g_ema.ema_model.state_dict().values(), b.net_g_ema.ema_model.state_dict().values()):
         assert torch.equal(va, vb)
+
+
+def test_span_step_matches_oracle(cuda):
+    """SPAN generator behind the trainer (the registry default `norm: false`, 2x): one L1 step in fp32 against the oracle's step."""
+    from oracle import losses as OL, span as OSP, step as OS
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], network_g=dict(type="span", feature_channels=16))
+    model = SRModel(opt)
+    hp = OSP.hparams(feature_channels=16, scale=4, norm=False)
+    sd = {k: v.detach().cpu().clone() for k, v in model.net_g.state_dict().items() if k != "no_norm"}
+    assert list(sd) == list(OSP.param_table(hp))
+    params = OrderedDict((k, v.clone().requires_grad_("eval_conv" not in k)) for k, v in sd.items())
+    train = OrderedDict((k, v) for k, v in params.items() if "eval_conv" not in k)
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in train.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    lq, gt = _data(seed=4)
+    _, ld, _, _ = OS.generator_step(train, lambda p, x: OSP.forward({**params, **p}, x, hp), OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, None)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 1e-5 * float(ld["l_g_l1"])
+    assert abs(log["grad_norm_g"] - float(ld["grad_norm_g"])) < 1e-4 * float(ld["grad_norm_g"])
+    sdm = model.net_g.state_dict()
+    e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in train.items())
+    print("span weights after one step", e_w)
+    assert e_w < 5e-4
