@@ -19,6 +19,7 @@
 //     dtype stores) works on 8/16-byte NHWC vectors.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -52,54 +53,55 @@ struct ConvArgs {
 
 
 // ---- 9 taps x one K-chunk of MFMAs out of the staged LDS image (hl: halo, wl: weight slab) --------------------------
+// Software pipelined over the 2 * KS * KS (tap, 16-byte slot pair) steps: the operand fragments of step s + 1 are read from LDS
+// before the MFMAs of step s issue, so a wave overlaps its own LDS latency instead of relying on the other resident wave
+// (the straight version waited on a fresh ds_read in front of every pair of MFMAs).
 template <int CT, int NT, int R, int KS = 3>
 __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int wv, int lr, int lh) {
     constexpr int CGW = NT * 32;
     constexpr int HALO_W = TW + KS - 1;
+    constexpr int NSTEP = KS * KS * 2;
+    typedef typename std::conditional<CT == TR_F32, f32x4, bf16x8>::type frag_t;
+    frag_t wa[2][NT], xb[2][R];
+#define TR_CONV_FRAGS(BUF, STEP)                                                                                        \
+    {                                                                                                                   \
+        const int tap_ = (STEP) >> 1, ky_ = tap_ / KS, kx_ = tap_ % KS, slot_ = ((STEP) & 1) * 2 + lh;                   \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                 \
+            const int row = tap_ * CGW + t * 32 + lr;                                                                    \
+            wa[BUF][t] = *(const frag_t*)(wl + row * 64 + ((slot_ ^ ((row >> 2) & 3)) << 4));                            \
+        }                                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                  \
+            const int pp = (wv * R + r + ky_) * HALO_W + lr + kx_;                                                       \
+            xb[BUF][r] = *(const frag_t*)(hl + pp * 64 + ((slot_ ^ ((pp >> 2) & 3)) << 4));                              \
+        }                                                                                                               \
+    }
+    // the 8-row / 32-channel variant lives on a 168-VGPR budget (three workgroups per CU): no second fragment set there
+    constexpr bool PIPE = !(NT == 1 && R == 2 && KS == 3);
+    if constexpr (PIPE) TR_CONV_FRAGS(0, 0)
 #pragma unroll
-    for (int tap = 0; tap < KS * KS; ++tap) {
-        const int ky = tap / KS, kx = tap % KS;
+    for (int s = 0; s < NSTEP; ++s) {
+        const int cur = PIPE ? (s & 1) : 0;
+        if constexpr (PIPE) {
+            if (s + 1 < NSTEP) TR_CONV_FRAGS(cur ^ 1, s + 1)
+        } else {
+            TR_CONV_FRAGS(0, s)
+        }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int slot = q * 2 + lh;
-            if constexpr (CT != TR_F32) {
-                bf16x8 wa[NT];
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int row = tap * CGW + t * 32 + lr;
-                    wa[t] = *(const bf16x8*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-                }
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (CT == TR_BF16) {
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][t], xb[cur][r], acc[r][t], 0, 0, 0);
+                } else if constexpr (CT == TR_F16) {
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[cur][t]), __builtin_bit_cast(f16x8, xb[cur][r]), acc[r][t], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
-                    const bf16x8 xb = *(const bf16x8*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if constexpr (CT == TR_BF16) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb, acc[r][t], 0, 0, 0);
-                        else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[t]), __builtin_bit_cast(f16x8, xb), acc[r][t], 0, 0, 0);
-                    }
-                }
-            } else {
-                f32x4 wa[NT];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int row = tap * CGW + t * 32 + lr;
-                    wa[t] = *(const f32x4*)(wl + row * 64 + ((slot ^ ((row >> 2) & 3)) << 4));
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
-                    const f32x4 xb = *(const f32x4*)(hl + pp * 64 + ((slot ^ ((pp >> 2) & 3)) << 4));
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t][e], xb[e], acc[r][t], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][t][e], xb[cur][r][e], acc[r][t], 0, 0, 0);
                 }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // bound the live operand fragments to one tap (VGPR budget)
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch exactly one step ahead (VGPR budget)
     }
+#undef TR_CONV_FRAGS
 }
 
 __device__ __forceinline__ float silu_grad(float x) {   // d/dx [x * sigmoid(x)]
