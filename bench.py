@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "f32"], help="f16 = the reference's default AMP mode: fp16 operands + loss scaling")
+    ap.add_argument("--fast-matmul", action="store_true", help="the reference's fast_matmul option: split-bf16 (3 bf16 MFMAs per product) for the fp32-forced VGG; NOT the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational fast_matmul measurement")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     swin = args.arch != "esrgan"
@@ -65,7 +67,7 @@ def make_opt(args):
     elif args.losses == "l1+perceptualfp16":
         losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
     return parse_options_dict(dict(
-        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
+        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, fast_matmul=args.fast_matmul, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
         network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=args.scale),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
@@ -252,7 +254,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
             "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
-                                   + f" {args.losses} {args.compute}, {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+                                   + f" {args.losses} {args.compute}" + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }
@@ -274,6 +276,25 @@ def main():
                                "avg_launch_ms": msum / cnt,
                                "share_of_step": msum / (dt * 1e3),
                                "all": {f"{k[0]}/cg{k[1]}" + ("" if k[2] == 3 else f"/k{k[2]}"): {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
+        if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
+            # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the
+            # split-bf16 path of the fp32-forced VGG head (3 bf16 MFMAs per product; measured 3e-6 rel-L2 per conv vs exact fp32)
+            head = model.losses.get("l_g_perceptual")
+            if head is not None and hasattr(head, "set_fast_matmul"):
+                head.set_fast_matmul(True)
+                it += 1
+                step(it)
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    it += 1
+                    step(it)
+                fence()
+                dt2 = time.perf_counter() - t1
+                head.set_fast_matmul(False)
+                out["variants"] = {"fast_matmul": {"value": n * args.steps / dt2, "unit": "images/sec", "ms_per_step": dt2 / args.steps * 1e3,
+                                                   "what": "same workload with the reference option fast_matmul: true (split-bf16 MFMAs in the fp32-forced "
+                                                           "VGG head; everything else unchanged); not the headline value"}}
         if not args.no_cpu_baseline and world == 1:
             log(f"cpu baseline on {host_threads()} threads")
             out["cpu_baseline"] = cpu_baseline(args, "perceptual" in args.losses)

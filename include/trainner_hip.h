@@ -34,7 +34,7 @@ extern "C" {
 
 #define TR_ABI_VERSION 1
 
-enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
+enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2, TR_BF16X3 = 3 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
 enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3, TR_ACT_SILU = 4 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
@@ -73,7 +73,10 @@ size_t      tr_conv_packed_bytes(int cin, int cout, int compute, int ksize);
  *   out = (out.dtype) v ; out2 = (out2.dtype)(v*out2_scale)   (out2 optional)
  *
  * compute = TR_BF16 / TR_F16: in.dtype must equal it, 16-bit operands, fp32 accumulate
- *           (v_mfma_f32_32x32x16_bf16 / _f16); compute = TR_F32: in.dtype TR_F32, exact fp32
+ *           (v_mfma_f32_32x32x16_bf16 / _f16); compute = TR_BF16X3 (3x3 only, fp32 views): the reference's `fast_matmul` trade
+ *           ("Trade precision for performance", redux_options.py:479-481; TF32 on its CUDA targets) done the gfx950 way, which has no
+ *           TF32: every fp32 operand is split on the fly into hi + lo bf16 and each product is 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi),
+ *           ~2^-17 relative per product -- between TF32 and fp32; compute = TR_F32: in.dtype TR_F32, exact fp32
  *           (v_mfma_f32_32x32x2_f32).  Epilogue arithmetic is always fp32.
  */
 typedef struct tr_conv3x3_desc {

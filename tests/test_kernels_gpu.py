@@ -444,3 +444,32 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     mref = mkd.float().cpu()[..., :k].reshape(-1, k).requires_grad_(True)
     F.gelu(mref).sum().backward()
     assert rel_l2(gx2[..., :k].reshape(-1, k).cpu(), ref_gx * mref.grad) < 3e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 37, 64, 64), (1, 16, 48, 8, 64), (1, 33, 40, 128, 32), (1, 12, 32, 256, 128)])
+def test_conv3x3_split_bf16_fast_matmul(cuda, shape):
+    """compute = TR_BF16X3 (the reference's `fast_matmul` trade, done without TF32): fp32 views, every product as hi*hi + hi*lo + lo*hi in
+    bf16 MFMAs.  Against the fp32 reference: rel-L2 <= 2e-5 (a bf16 conv of the same data sits at ~3e-3, TF32 at ~5e-4)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(77 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))
+    xd, bd = nhwc(x).to(cuda), b.to(cuda)
+    wp = pack(ops, L, wt.to(cuda), cin, cout, L.BF16X3, cuda)
+    out = torch.empty(n, h, w, cout, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.BF16X3, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bd, act=L.ACT_RELU)
+    e = rel_l2(nchw(out.cpu()), ref)
+    e_bf = rel_l2(F.relu(F.conv2d(bf(x), bf(wt), b, padding=1)), ref)
+    print(f"split-bf16 {shape}: rel-L2 {e:.2e} (plain bf16 operands: {e_bf:.2e})")
+    assert e < 2e-5, e
+    # input gradient through the transposed slab in the same mode
+    gy = torch.randn(n, cout, h, w, generator=g)
+    wpt = pack(ops, L, wt.to(cuda), cout, cin, L.BF16X3, cuda, transpose=True)
+    gyd = nhwc(gy).to(cuda)
+    gx = torch.empty(n, h, w, cin, dtype=torch.float32, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.BF16X3, inp=ops.view(gyd), out=ops.view(gx), wpacked=wpt)
+    assert rel_l2(nchw(gx.cpu()), torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=1)) < 2e-5

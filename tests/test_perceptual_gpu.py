@@ -92,3 +92,39 @@ def test_perceptual_autograd_bridge(cuda):
         assert abs(float(out[k]) - float(ref[k])) < 2e-5 * float(ref[k])
     (sum(out.values()) * 2.0).backward()   # upstream scale goes through the per-layer scales of the bridge
     assert rel_l2(xd.grad.cpu(), 2 * xr.grad) < 2e-4
+
+
+def test_perceptual_fast_matmul_split_bf16(cuda):
+    """`fast_matmul: true` (the reference's "trade precision for performance" switch; TF32 on its CUDA targets) = split-bf16 MFMAs in the
+    fp32-forced VGG head: per-layer values within 5e-5 of the fp32 oracle (measured 5e-6; total 5e-7), d(loss)/dx cosine >= 0.9999 / rel-L2 <= 1e-2 (a near-tied max-pool
+    window re-routes one gradient path under 3e-6 of noise, see above)
+    -- two orders of magnitude tighter than the bf16 head, far inside north_star's 1e-3 on the loss."""
+    import warnings
+
+    from oracle import vgg as OV
+    from oracle.precision import FP32
+    from trainner_redux_amd.losses import build_loss
+
+    sd = OV.synthetic_state_dict(3)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 32, 48, generator=g).requires_grad_(True)
+    gt = torch.rand(2, 3, 32, 48, generator=g)
+    ref = OV.perceptual_loss(sd, x, gt, criterion="charbonnier", policy=FP32)
+    w = 0.01
+    tot_ref = sum(v * w for v in ref.values())
+    (gref,) = torch.autograd.grad(tot_ref, x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loss = build_loss(dict(type="perceptualloss", loss_weight=w, criterion="charbonnier")).to(cuda)
+    loss.vgg.load_torchvision_state_dict(sd)
+    loss.set_compute_dtype(torch.bfloat16)
+    loss.set_fast_matmul(True)
+    vals, total = torch.zeros(8, device=cuda), torch.zeros(1, device=cuda)
+    xd, gtd = x.detach().to(cuda), gt.to(cuda)
+    grad = torch.zeros_like(xd)
+    names = loss.hip_value_and_grad(xd, gtd, value_weight=w, value_out=vals, total_weight=w, total_out=total, grad_weight=w, grad=grad, first=True)
+    worst = max(abs(vals[j].item() - float(ref[k]) * w) / (float(ref[k]) * w) for j, k in enumerate(names))
+    e = rel_l2(grad.cpu(), gref)
+    print(f"fast_matmul perceptual: worst layer value rel {worst:.2e}, total rel {abs(total.item() - float(tot_ref)) / float(tot_ref):.2e}, grad rel-L2 {e:.2e}")
+    cos = torch.nn.functional.cosine_similarity(grad.cpu().flatten().double(), gref.flatten().double(), dim=0).item()
+    assert worst < 5e-5 and e < 1e-2 and cos > 0.9999, (worst, e, cos)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
-F32, BF16, F16 = 0, 1, 2
+F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 IN_DIRECT, IN_NEAREST2X, IN_FULL, IN_VALID = 0, 1, 2, 3

@@ -118,8 +118,8 @@ struct PackGeom {
 };
 __host__ __device__ inline PackGeom pack_geom(int cin, int cout, int compute) {
     PackGeom g;
-    g.ck = compute == TR_F32 ? 16 : 32;
-    g.eps = compute == TR_F32 ? 4 : 8;
+    g.ck = (compute == TR_F32 || compute == TR_BF16X3) ? 16 : 32;     // 64-byte rows: 16 fp32, 16 x (hi + lo) bf16, or 32 16-bit channels
+    g.eps = (compute == TR_F32 || compute == TR_BF16X3) ? 4 : 8;
     g.cgw = cout > 32 ? 64 : 32;
     g.ncg = (cout + g.cgw - 1) / g.cgw;
     g.nchunks = (cin + g.ck - 1) / g.ck;

@@ -60,6 +60,37 @@ template <int CT, int NT, int R, int KS = 3>
 __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int wv, int lr, int lh) {
     constexpr int CGW = NT * 32;
     constexpr int HALO_W = TW + KS - 1;
+    if constexpr (CT == TR_BF16X3) {
+        // split-bf16 "fp32": a row holds 16 channels as [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] (16-byte slots, same swizzle), so one tap
+        // is ONE 16-deep MFMA step per operand pairing: acc += w_hi*x_hi + w_hi*x_lo + w_lo*x_hi   (lo*lo ~ 2^-18 is dropped)
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            bf16x8 wh[NT], wlo[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int row = tap * CGW + t * 32 + lr;
+                const int sw = (row >> 2) & 3;
+                wh[t] = *(const bf16x8*)(wl + row * 64 + ((lh ^ sw) << 4));
+                wlo[t] = *(const bf16x8*)(wl + row * 64 + (((2 + lh) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int pp = (wv * R + r + ky) * HALO_W + lr + kx;
+                const int sw = (pp >> 2) & 3;
+                const bf16x8 xh = *(const bf16x8*)(hl + pp * 64 + ((lh ^ sw) << 4));
+                const bf16x8 xl = *(const bf16x8*)(hl + pp * 64 + (((2 + lh) ^ sw) << 4));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo[t], xh, acc[r][t], 0, 0, 0);
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], xl, acc[r][t], 0, 0, 0);
+                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[t], xh, acc[r][t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     constexpr int NSTEP = KS * KS * 2;
     typedef typename std::conditional<CT == TR_F32, f32x4, bf16x8>::type frag_t;
     frag_t wa[2][NT], xb[2][R];
@@ -102,6 +133,13 @@ __device__ __forceinline__ void conv_chunk_mfma(const char* hl, const char* wl, 
         __builtin_amdgcn_sched_barrier(0);   // keep the prefetch exactly one step ahead (VGPR budget)
     }
 #undef TR_CONV_FRAGS
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2c;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2c;
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {   // element 0 in the low half
+    const f32x2c v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2c));
 }
 
 __device__ __forceinline__ float silu_grad(float x) {   // d/dx [x * sigmoid(x)]
@@ -247,7 +285,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
 // already in flight into registers, so neither the first-load latency of a tile nor its epilogue stores are exposed.
 // One LDS stage; two workgroups per CU cover each other's LDS write phases.
 template <int CT, int NT, int R, int KS>
-__global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && CT != TR_F32) ? 3 : 2) void conv3x3_kernel_reg(ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && (CT == TR_BF16 || CT == TR_F16)) ? 3 : 2) void conv3x3_kernel_reg(ConvArgs a) {
     constexpr int TH = 4 * R;
     constexpr int PAD = KS / 2;                        // KS = 3: 3x3 pad 1 ; KS = 1: 1x1 (token GEMMs: Linear layers)
     constexpr int HALO_W = TW + KS - 1;
@@ -256,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && CT != TR_F32) ? 3 :
     constexpr int HALO_BYTES = HALO_PIX * 64;
     constexpr int CGW = NT * 32;
     constexpr int W_ITEMS = KS * KS * CGW * 4;
-    constexpr int ES = CT == TR_F32 ? 4 : 2;
+    constexpr int ES = (CT == TR_F32 || CT == TR_BF16X3) ? 4 : 2;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
     constexpr int HALO_IT = (HALO_ITEMS + NTHREADS - 1) / NTHREADS;
@@ -274,6 +312,8 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && CT != TR_F32) ? 3 :
     const int s_slot = tid & 3;
     const int pp0 = tid >> 2;
     const int lds0 = pp0 * 64 + ((s_slot ^ ((pp0 >> 2) & 3)) << 4);
+    const int ldsx_hi = pp0 * 64 + ((((s_slot >> 1)) ^ ((pp0 >> 2) & 3)) << 4) + (s_slot & 1) * 8;        // TR_BF16X3 split rows
+    const int ldsx_lo = pp0 * 64 + (((2 + (s_slot >> 1)) ^ ((pp0 >> 2) & 3)) << 4) + (s_slot & 1) * 8;
     const char* in_base = (const char*)a.in.ptr + (int64_t)(a.in.coff + s_slot * EPS) * ES;
     const int64_t in_pix_bytes = (int64_t)a.in.cstride * ES;
     const int ntiles = a.ntx * a.nty * a.n * a.ncg;
@@ -373,7 +413,19 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && CT != TR_F32) ? 3 :
             __syncthreads();   // every wave has finished reading the previous LDS image (or the previous tile's epilogue strips)
 #pragma unroll
             for (int j = 0; j < HALO_IT; ++j)
-                if ((HALO_ITEMS % NTHREADS == 0) || (pp0 + 64 * j < HALO_PIX)) *(uint4*)(hl + lds0 + 4096 * j) = hreg[j];
+                if ((HALO_ITEMS % NTHREADS == 0) || (pp0 + 64 * j < HALO_PIX)) {
+                    if constexpr (CT == TR_BF16X3) {
+                        // 4 fp32 channels -> 4 bf16 hi + 4 bf16 lo; piece s covers channels 4s..4s+3: hi bytes [8s, 8s+8), lo bytes 32 + [8s, 8s+8)
+                        const float f0 = __uint_as_float(hreg[j].x), f1 = __uint_as_float(hreg[j].y), f2 = __uint_as_float(hreg[j].z), f3 = __uint_as_float(hreg[j].w);
+                        const unsigned h01 = pack_bf16x2(f0, f1), h23 = pack_bf16x2(f2, f3);
+                        const unsigned l01 = pack_bf16x2(f0 - __uint_as_float(h01 << 16), f1 - __uint_as_float(h01 & 0xffff0000u));
+                        const unsigned l23 = pack_bf16x2(f2 - __uint_as_float(h23 << 16), f3 - __uint_as_float(h23 & 0xffff0000u));
+                        *(uint2*)(hl + ldsx_hi + 4096 * j) = make_uint2(h01, h23);
+                        *(uint2*)(hl + ldsx_lo + 4096 * j) = make_uint2(l01, l23);
+                    } else {
+                        *(uint4*)(hl + lds0 + 4096 * j) = hreg[j];
+                    }
+                }
 #pragma unroll
             for (int j = 0; j < W_IT; ++j)
                 if ((W_ITEMS % NTHREADS == 0) || (tid + j * NTHREADS < W_ITEMS)) *(uint4*)(wl + tid * 16 + j * (NTHREADS * 16)) = wreg[j];
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
     constexpr int W_IT = (W_ITEMS + NTHREADS - 1) / NTHREADS;
     constexpr int W_BYTES = W_IT * NTHREADS * 16;
     constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;
-    constexpr int ES = CT == TR_F32 ? 4 : 2;
+    constexpr int ES = (CT == TR_F32 || CT == TR_BF16X3) ? 4 : 2;
     constexpr int EPS = 16 / ES;                       // elements per slot
     constexpr int CK = 64 / ES;                        // channels per chunk
     constexpr unsigned OOB = 0x7fffff00u;              // beyond any num_records: the buffer load returns 0
@@ -516,7 +568,7 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
     // resident workgroups: 2 per CU, or 3 for the 8-row / 32-channel tile (164 VGPRs, 40 KB LDS) -- measured +15 % on the thin
     // RDB convs (cin <= 96), whose K loop is too short to hide the load latency with two workgroups
     static const int persist_env = getenv("TRAINNER_CONV_WGS") ? atoi(getenv("TRAINNER_CONV_WGS")) : 0;
-    const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && CT != TR_F32) ? 768 : 512);
+    const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && (CT == TR_BF16 || CT == TR_F16)) ? 768 : 512);
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
     const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
     hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R, KS>), dim3(grid), dim3(NTHREADS), lds, st, a);
@@ -534,7 +586,7 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
 template <int CT, int NCG>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(ConvArgs a, int nblk) {
     constexpr int R = 2, NT = NCG;
-    constexpr int ES = CT == TR_F32 ? 4 : 2;
+    constexpr int ES = (CT == TR_F32 || CT == TR_BF16X3) ? 4 : 2;
     constexpr int EPS = 16 / ES;
     constexpr int CK = 64 / ES;
     constexpr int X_BYTES = 128 * 64;
@@ -644,11 +696,12 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_conv3x3: null descriptor");
     TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, TR_EINVAL,
                "tr_conv3x3: bad dims n=%d h=%d w=%d cin=%d cout=%d", d->n, d->h, d->w, d->cin, d->cout);
-    TR_REQUIRE(d->compute == TR_F32 || d->compute == TR_BF16 || d->compute == TR_F16, TR_EINVAL, "tr_conv3x3: bad compute dtype %d", d->compute);
+    TR_REQUIRE(d->compute >= TR_F32 && d->compute <= TR_BF16X3, TR_EINVAL, "tr_conv3x3: bad compute dtype %d", d->compute);
+    TR_REQUIRE(d->compute != TR_BF16X3 || d->ksize == 3, TR_EUNSUPPORTED, "tr_conv3x3: split-bf16 (fast_matmul) mode is built for 3x3 only");
     TR_REQUIRE(d->in.ptr && d->out.ptr && d->wpacked, TR_EINVAL, "tr_conv3x3: in/out/wpacked must be set");
-    TR_REQUIRE(d->in.dtype == d->compute, TR_EUNSUPPORTED, "tr_conv3x3: input dtype %d must equal compute dtype %d",
+    TR_REQUIRE(d->in.dtype == (d->compute == TR_BF16X3 ? TR_F32 : d->compute), TR_EUNSUPPORTED, "tr_conv3x3: input dtype %d does not fit compute dtype %d",
                d->in.dtype, d->compute);
-    const int eps = d->compute == TR_F32 ? 4 : 8;
+    const int eps = (d->compute == TR_F32 || d->compute == TR_BF16X3) ? 4 : 8;
     TR_REQUIRE(d->cin % eps == 0, TR_EALIGN, "tr_conv3x3: cin=%d must be a multiple of %d (pad the view)", d->cin, eps);
     TR_REQUIRE(view_ok(d->in, d->cin), TR_EINVAL, "tr_conv3x3: input view does not hold cin=%d channels", d->cin);
     TR_REQUIRE(tr::view_vec16B_ok(d->in), TR_EALIGN, "tr_conv3x3: input view is not 16-byte sliceable");
@@ -699,7 +752,7 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     const bool roomy = a.h >= 16 && (int64_t)d->n * ((a.h + 15) / 16) * a.ntx * g.ncg >= 512;
     TR_REQUIRE(d->ksize == 3 || d->ksize == 1, TR_EUNSUPPORTED, "tr_conv3x3: ksize must be 3 or 1 (got %d)", d->ksize);
     TR_REQUIRE(d->ksize == 3 || (d->in_mode != TR_IN_NEAREST2X && d->pad_mode == TR_PAD_ZEROS), TR_EINVAL, "tr_conv3x3: 1x1 mode takes direct / full / valid input");
-    if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID && d->compute != TR_F16) {
+    if (use_dma && d->ksize == 3 && d->in_mode != TR_IN_VALID && d->compute != TR_F16 && d->compute != TR_BF16X3) {
         TR_REQUIRE((int64_t)a.hin * a.win * d->in.cstride * tr::esize(d->in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
                    "tr_conv3x3: one image of the input view must stay below 2 GiB (buffer addressing)");
         const bool big = force_r ? force_r == 4 : roomy;
@@ -713,9 +766,10 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     }
     // register-staged: 32-wide output groups take 16-row tiles (twice the MFMAs per staged weight slab); 64-wide groups
     // keep 8-row tiles, whose accumulators + prefetch registers already fill the 256-VGPR budget of two workgroups per CU.
-    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : (roomy && !(d->compute != TR_F32 && d->ksize == 3 && d->cin <= 96)));
+    const bool big = g.cgw == 32 && (force_r ? force_r == 4 : (roomy && !((d->compute == TR_BF16 || d->compute == TR_F16) && d->ksize == 3 && d->cin <= 96)));
     const int ct = d->compute;
 #define TR_BY_CT(FN, ...) (ct == TR_BF16 ? FN<TR_BF16, __VA_ARGS__> : ct == TR_F16 ? FN<TR_F16, __VA_ARGS__> : FN<TR_F32, __VA_ARGS__>)
+#define TR_BY_CT3(FN, ...) (ct == TR_BF16X3 ? FN<TR_BF16X3, __VA_ARGS__> : TR_BY_CT(FN, __VA_ARGS__))
     static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
     if (d->ksize == 1 && a.w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
         // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
@@ -736,9 +790,10 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     }
     if (big) {
         a.nty = (a.h + 15) / 16;
-        return TR_BY_CT(launch_reg, 1, 4, 3)(st, a, g.ncg);
+        return TR_BY_CT3(launch_reg, 1, 4, 3)(st, a, g.ncg);
     }
     a.nty = (a.h + 7) / 8;
-    return g.cgw == 64 ? TR_BY_CT(launch_reg, 2, 2, 3)(st, a, g.ncg) : TR_BY_CT(launch_reg, 1, 2, 3)(st, a, g.ncg);
+    return g.cgw == 64 ? TR_BY_CT3(launch_reg, 2, 2, 3)(st, a, g.ncg) : TR_BY_CT3(launch_reg, 1, 2, 3)(st, a, g.ncg);
+#undef TR_BY_CT3
 #undef TR_BY_CT
 }

@@ -36,12 +36,22 @@ __global__ __launch_bounds__(256) void pack_kernel(const tr_pack_seg* __restrict
         const tr::PackGeom g = tr::pack_geom(s.dst_cin, s.dst_cout, s.compute);
         const int cg = co / g.cgw, col = co - cg * g.cgw;
         const int chunk = ci / g.ck, cil = ci - chunk * g.ck;
-        const int slot = cil / g.eps, e = cil - slot * g.eps;
         const int row = tp * g.cgw + col;
-        const int64_t off = (((int64_t)cg * g.nchunks + chunk) * kk * g.cgw + row) * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-        char* dst = (char*)s.dst + off;
-        if (s.compute != TR_F32) ((unsigned short*)dst)[e] = tr::f32_to_h(val, s.compute);
-        else ((float*)dst)[e] = val;
+        char* rowp = (char*)s.dst + (((int64_t)cg * g.nchunks + chunk) * kk * g.cgw + row) * 64;
+        const int swz = (row >> 2) & 3;
+        if (s.compute == TR_BF16X3) {
+            // split row: bytes [0, 32) = bf16 hi of the 16 channels, [32, 64) = bf16 lo (val - hi), same slot swizzle
+            const unsigned short hi = tr::f32_to_bf16(val);
+            const unsigned short lo = tr::f32_to_bf16(val - tr::bf16_to_f32(hi));
+            const int bh = cil * 2, bl = 32 + cil * 2;
+            *(unsigned short*)(rowp + ((((bh >> 4) ^ swz) & 3) << 4) + (bh & 15)) = hi;
+            *(unsigned short*)(rowp + ((((bl >> 4) ^ swz) & 3) << 4) + (bl & 15)) = lo;
+        } else {
+            const int slot = cil / g.eps, e = cil - slot * g.eps;
+            char* dst = rowp + ((slot ^ swz) << 4);
+            if (s.compute != TR_F32) ((unsigned short*)dst)[e] = tr::f32_to_h(val, s.compute);
+            else ((float*)dst)[e] = val;
+        }
     }
 }
 

@@ -251,7 +251,7 @@ class VGG(nn.Module):
 
     def loss_and_grad(self, x: Tensor, gt: Tensor, *, layer_weights: dict, kind: int, eps: float, compute_dtype, value_weight: float,
                       value_out: Tensor, total_weight: float, total_out: Tensor | None, grad_weight: float, grad: Tensor | None,
-                      first: bool, layer_grad_scale: dict[str, float] | None = None) -> list[str]:
+                      first: bool, layer_grad_scale: dict[str, float] | None = None, compute_code: int | None = None) -> list[str]:
         """value_out[j] = value_weight * lw_j * crit(F_j(x), F_j(gt)); total_out[0] += total_weight * (same);
         grad (+)= grad_weight * d(sum_j lw_j crit_j)/dx.  Returns the tapped layer names in value order."""
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape == gt.shape and x.shape[1] == 3
@@ -260,7 +260,7 @@ class VGG(nn.Module):
         if h % (1 << npool) or w % (1 << npool):
             raise ValueError(f"perceptual head needs H, W divisible by {1 << npool} (got {h}x{w})")
         dev = x.device
-        cd = ops.dt_code(compute_dtype)
+        cd = ops.dt_code(compute_dtype) if compute_code is None else compute_code     # L.BF16X3: fp32 buffers, split-bf16 MFMAs
         pk = self._pack(cd, dev)
         ws = self._workspace(n, h, w, compute_dtype, dev)
         V = ops.view
@@ -352,6 +352,7 @@ class PerceptualFP16Loss(nn.Module):
         self.criterion = criterion
         self.kind = L.LOSS_L1 if criterion == "l1" else L.LOSS_CHARBONNIER
         self.compute_dtype = torch.float32
+        self.fast_matmul = False
         if self.vgg.synthetic:
             warnings.warn("VGG19 weights not found (set TRAINNER_VGG19_WEIGHTS to a torchvision vgg19 state dict); "
                           "the perceptual head uses seeded synthetic weights", stacklevel=2)
@@ -360,11 +361,21 @@ class PerceptualFP16Loss(nn.Module):
         """`perceptualloss` ignores AMP (fp32 forced, perceptual_loss.py:10); `perceptualfp16loss` follows it."""
         self.compute_dtype = torch.float32 if self.force_fp32 else dtype
 
+    def set_fast_matmul(self, on: bool) -> None:
+        """The reference's `fast_matmul` option ("Trade precision for performance", redux_options.py:479-481: TF32 matmuls on its CUDA
+        targets).  gfx950 has no TF32; the equivalent here is split-bf16: the fp32-forced VGG keeps fp32 activations and weights but
+        every product runs as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), ~2^-17 relative per product (TF32: 2^-11)."""
+        self.fast_matmul = bool(on)
+
+    def _compute_code(self):
+        return L.BF16X3 if (self.fast_matmul and self.compute_dtype == torch.float32) else None
+
     def hip_value_and_grad(self, pred: Tensor, target: Tensor, *, value_weight: float, value_out: Tensor, total_weight: float,
                            total_out: Tensor | None, grad_weight: float, grad: Tensor | None, first: bool) -> list[str]:
         return self.vgg.loss_and_grad(pred, target, layer_weights=self.layer_weights, kind=self.kind, eps=1e-12,
                                       compute_dtype=self.compute_dtype, value_weight=value_weight, value_out=value_out,
-                                      total_weight=total_weight, total_out=total_out, grad_weight=grad_weight, grad=grad, first=first)
+                                      total_weight=total_weight, total_out=total_out, grad_weight=grad_weight, grad=grad, first=first,
+                                      compute_code=self._compute_code())
 
     def forward(self, x: Tensor, gt: Tensor) -> dict[str, Tensor]:
         vals = _PerceptualFn.apply(x, gt, self)

@@ -169,6 +169,8 @@ class SRModel:
                 self.losses[label] = build_loss(loss).to(self.device)
                 if hasattr(self.losses[label], "set_compute_dtype"):
                     self.losses[label].set_compute_dtype(self.compute_dtype)
+                if hasattr(self.losses[label], "set_fast_matmul"):
+                    self.losses[label].set_fast_matmul(bool(getattr(self.opt, "fast_matmul", False)))
         assert self.losses, "At least one loss must be defined."
         self.setup_optimizers()
         self.setup_schedulers()
