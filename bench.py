@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--blocks", type=int, default=23)
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "f32"], help="f16 = the reference's default AMP mode: fp16 operands + loss scaling")
+    ap.add_argument("--gan", action="store_true", help="BASELINE.json configs[2] heads: add the UNetDiscriminatorSN + vanilla GAN term (weight 0.1) and its D update")
     ap.add_argument("--fast-matmul", action="store_true", help="the reference's fast_matmul option: split-bf16 (3 bf16 MFMAs per product) for the fp32-forced VGG; NOT the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational fast_matmul measurement")
@@ -66,13 +67,20 @@ def make_opt(args):
         losses.append(dict(type="perceptualloss", loss_weight=0.01, criterion="charbonnier"))
     elif args.losses == "l1+perceptualfp16":
         losses.append(dict(type="perceptualfp16loss", loss_weight=0.01, criterion="charbonnier"))
+    extra = {}
+    train_extra = {}
+    if args.gan:
+        losses.append(dict(type="ganloss", gan_type="vanilla", loss_weight=0.1))
+        extra["network_d"] = dict(type="unetdiscriminatorsn")
+        train_extra["optim_d"] = dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99])
     return parse_options_dict(dict(
+        **extra,
         name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, fast_matmul=args.fast_matmul, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
         network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=args.scale),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
                    optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
-                   scheduler=dict(type="MultiStepLR", milestones=[500000], gamma=0.5), losses=losses),
+                   scheduler=dict(type="MultiStepLR", milestones=[500000], gamma=0.5), losses=losses, **train_extra),
     ))
 
 
@@ -254,7 +262,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
             "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
-                                   + f" {args.losses} {args.compute}" + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+                                   + f" {args.losses} {args.compute}" + (" +GAN(UNetDiscriminatorSN)" if args.gan else "") + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }
