@@ -36,7 +36,7 @@ extern "C" {
 
 enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2, TR_BF16X3 = 3 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
-enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3, TR_ACT_SILU = 4 };
+enum { TR_ACT_NONE = 0, TR_ACT_LRELU = 1, TR_ACT_RELU = 2, TR_ACT_GELU = 3, TR_ACT_SILU = 4, TR_ACT_MISH = 5 };
 enum { TR_PAD_ZEROS = 0, TR_PAD_REPLICATE = 1 };
 enum { TR_IN_DIRECT = 0, TR_IN_NEAREST2X = 1, TR_IN_FULL = 2, TR_IN_VALID = 3 };
 enum { TR_LOSS_L1 = 0, TR_LOSS_MSE = 1, TR_LOSS_CHARBONNIER = 2 };
@@ -100,9 +100,9 @@ typedef struct tr_conv3x3_desc {
     const float* bias;        /* cout floats or NULL                                          */
     int32_t ksize;            /* 3 (3x3, pad 1) or 1 (1x1: nn.Linear over tokens laid out as an n x h x w grid,
                                  traiNNer/archs/drct_arch.py:64-66,166-168)                     */
-    int32_t mask_mode;        /* 0: LeakyReLU/ReLU derivative by sign ; 1: exact-GELU derivative of `mask` ; 2: SiLU derivative */
+    int32_t mask_mode;        /* 0: LeakyReLU/ReLU derivative by sign ; 1: exact-GELU derivative of `mask` ; 2: SiLU derivative ; 3: Mish derivative */
     const float* sample_scale;/* optional n floats multiplied into v per image before res1 (DropPath keep mask,
-                                 drct_arch.py:572-573); with act = TR_ACT_GELU / TR_ACT_SILU, out2 receives the pre-activation */
+                                 drct_arch.py:572-573); with act = TR_ACT_GELU / TR_ACT_SILU / TR_ACT_MISH, out2 receives the pre-activation */
 } tr_conv3x3_desc;
 
 int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
@@ -328,6 +328,24 @@ int tr_adamw_ema(void* stream, const tr_adamw_desc* d);
  *   g_o3 = g * (sim_att + (o3 + x) * s * (1 - s)),  g_x = g * sim_att   (s = sigmoid(o3)); gx (+)= when accumulate_gx != 0. */
 int tr_span_gate(void* stream, tr_view o3, tr_view x, tr_view out, tr_view out2, int64_t npix);
 int tr_span_gate_bwd(void* stream, tr_view g, tr_view o3, tr_view x, tr_view g_o3, tr_view g_x, int accumulate_gx, int64_t npix);
+
+/* ---- MoSR GatedCNNBlock pieces (spandrel MoSR -- absent wheel; in-tree twins of the block: archs/mosrv2_arch.py:88-126,
+ * archs/moesr_arch.py:66-106; factory arguments archs/mosr_arch.py:23-74) ------------------------------------------------------------
+ * tr_dwconv: nn.Conv2d(c, c, k, 1, k // 2, groups=c) on an NHWC channel slice; weight is the fp32 OIHW tensor (c x 1 x k x k), bias c floats
+ *            or NULL; flip != 0 mirrors the taps (= the input gradient of the same conv; pass bias NULL).  k in {3, 5, 7}, c % 4 == 0.
+ * tr_dwconv_wgrad: dw[c][ky][kx] (+)= sum gy[p][c] * in[p + (ky - k/2, kx - k/2)][c], db[c] (+)= sum gy[p][c]; fixed-order reduction
+ *            through `partials` (tr_dwconv_wgrad_workspace_bytes), bitwise reproducible.
+ * tr_gate_mish: out = mish(g) * cat(a, b)   (`self.act(g) * torch.cat((i, c), dim=1)`, mosrv2_arch.py:124), nn.Mish = x * tanh(softplus(x)).
+ * tr_gate_mish_bwd: given d = d/d(out): dg = d * cat(a, b) * mish'(g) ; da | db = d * mish(g).
+ * tr_act_grad: out = g * s[p / pix_per_sample] * act'(pre) for act = TR_ACT_MISH / TR_ACT_SILU (the gradient entering a conv whose output
+ *            went through the activation, when no producing conv can carry the mask in its epilogue); s = optional n floats (DropPath keep mask). */
+int    tr_dwconv(void* stream, tr_view in, tr_view out, const float* weight, const float* bias, int n, int h, int w, int c, int ksize, int flip);
+size_t tr_dwconv_wgrad_workspace_bytes(int n, int h, int w, int c, int ksize);
+int    tr_dwconv_wgrad(void* stream, tr_view in, tr_view gy, float* dw, float* db, int n, int h, int w, int c, int ksize, int accumulate,
+                       float* partials, size_t partials_bytes);
+int    tr_gate_mish(void* stream, tr_view g, tr_view a, tr_view b, tr_view out, int64_t npix);
+int    tr_gate_mish_bwd(void* stream, tr_view d, tr_view g, tr_view a, tr_view b, tr_view dg, tr_view da, tr_view db, int64_t npix);
+int    tr_act_grad(void* stream, int act, tr_view g, tr_view pre, tr_view out, int64_t npix, const float* sample_scale, int64_t pix_per_sample);
 
 /* ---- feed: uint8 HWC image batch (what a decoder produces; 4x fewer PCIe bytes than the reference's fp32 CHW DataFeed,
  * paired_image_dataset.py:133-146) -> fp32 NCHW in [0,1], optionally (x/255 - mean[c]) / std[c] (torchvision normalize, :141-143) */

@@ -123,6 +123,12 @@ def test_plugin_surface_names_and_checksums():
     assert sum(p.numel() for p in n.parameters()) == 16_697_987
     assert sum(p.numel() for p in build_network({"type": "esrgan", "scale": 2}).parameters()) == 16_703_171
     assert sum(p.numel() for p in build_network({"type": "esrgan_lite", "scale": 4}).parameters()) == 5_021_155
+    from trainner_redux_amd.utils.registry import ARCH_REGISTRY
+    assert {"mosr", "mosr_t"} <= set(ARCH_REGISTRY.keys())       # archs/mosr_arch.py:23,50 registers them in ARCH_REGISTRY
+    for name, sc, cnt in (("mosr", 4, 4_287_600), ("mosr", 2, 4_266_828), ("mosr_t", 4, 609_888), ("mosr_t", 2, 594_300)):   # benchmarks.md:43,226,29,211
+        assert sum(p.numel() for p in build_network({"type": name, "scale": sc}).parameters()) == cnt
+    with pytest.raises(NotImplementedError):
+        build_network({"type": "mosr", "scale": 2, "upsampler": "dysample"})
     assert loss_type_to_label("L1Loss") == "l_g_l1" and loss_type_to_label("PerceptualLoss") == "l_g_perceptual"
     assert loss_type_to_label("multiscaleganloss") == "l_g_gan"
     l1 = build_loss({"type": "l1loss", "loss_weight": 0.5})
@@ -247,7 +253,7 @@ def test_mfma_kernels_keep_accumulators_in_registers():
 
     B.build(verbose=False)
     res = json.load(open(B.RESOURCES))
-    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn"))}
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn", "dwconv"))}
     assert len(hot) >= 20
     bad = {k: v["scratch"] for k, v in hot.items() if v.get("scratch", 0) != 0 or v.get("vgpr_spill", 0) != 0}
     assert not bad, bad

@@ -177,3 +177,26 @@ def test_span_oracle_matches_reference_module_goldens():
             for name in OS.conv3xc_names(hp):
                 w, b = OS.merged_kernel(sd, name)
                 assert rel_l2(w, e["state_eval"][name + ".eval_conv.weight"]) < 1e-6 and rel_l2(b, e["state_eval"][name + ".eval_conv.bias"]) < 1e-6
+
+
+def test_mosr_oracle_reproduces_every_published_parameter_count():
+    """spandrel's MoSR is absent: the restated structure is anchored on the reference's own checksums
+    (docs/source/benchmarks.md:43,132,226,315 mosr 4x / 3x / 2x / 1x; :29,117,211 mosr_t)."""
+    from oracle import mosr as OM
+
+    want = {("mosr", 4): 4_287_600, ("mosr", 3): 4_275_483, ("mosr", 2): 4_266_828, ("mosr", 1): 4_261_635,
+            ("mosr_t", 4): 609_888, ("mosr_t", 3): 600_795, ("mosr_t", 2): 594_300}
+    for (name, sc), cnt in want.items():
+        assert OM.num_params(OM.hparams(scale=sc, **OM.PRESETS[name])) == cnt, (name, sc)
+    hp = OM.hparams(scale=2, n_block=2, dim=16)
+    sd = OM.init_params(hp, 0, std=0.1, bias_std=0.1)
+    for v in sd.values():
+        v.requires_grad_(True)
+    x = torch.rand(2, 3, 12, 10)
+    y = OM.forward(sd, x, hp)
+    assert y.shape == (2, 3, 24, 20)                                    # tests/test_archs/test_archs.py:148-268: shape = scale x, finite
+    y.square().mean().backward()
+    assert all(torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0 for v in sd.values())
+    keep = {1: torch.tensor([0.0, 2.0])}                                # a dropped sample passes through its block unchanged
+    y0 = OM.forward(sd, x, hp, keep_masks=keep)
+    assert torch.isfinite(y0).all() and not torch.allclose(y0[1], y[1])

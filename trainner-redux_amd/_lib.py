@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
-ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4, 5
 PAD_ZEROS, PAD_REPLICATE = 0, 1
 IN_DIRECT, IN_NEAREST2X, IN_FULL, IN_VALID = 0, 1, 2, 3
 LOSS_L1, LOSS_MSE, LOSS_CHARBONNIER = 0, 1, 2
@@ -134,6 +134,12 @@ SYMBOLS = {
     "tr_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
     "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
+    "tr_dwconv": (C.c_int, [C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_dwconv_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_dwconv_wgrad": (C.c_int, [C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "tr_gate_mish": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
+    "tr_gate_mish_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, View, View, C.c_int64]),
+    "tr_act_grad": (C.c_int, [C.c_void_p, C.c_int, View, View, View, C.c_int64, C.c_void_p, C.c_int64]),
     "tr_space_to_depth2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
     "tr_depth_to_space2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int]),
     "tr_expand_w4x4s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

@@ -44,6 +44,19 @@ __device__ __forceinline__ unsigned short f32_to_f16(float f) { return __builtin
 __device__ __forceinline__ float h_to_f32(unsigned short h, int dtype) { return dtype == TR_BF16 ? bf16_to_f32(h) : f16_to_f32(h); }
 __device__ __forceinline__ unsigned short f32_to_h(float f, int dtype) { return dtype == TR_BF16 ? f32_to_bf16(f) : f32_to_f16(f); }
 
+// nn.Mish: x * tanh(softplus(x)), softplus with torch's threshold 20 (the in-tree twins of MoSR's block: mosrv2_arch.py:101,
+// moesr_arch.py:82).  With e = exp(x), n = e (e + 2): tanh(log(1 + e)) = n / (n + 2).
+__device__ __forceinline__ float mish(float x) {
+    if (x > 20.f) return x;
+    const float e = __expf(x), n = e * (e + 2.f);
+    return x * (n / (n + 2.f));
+}
+__device__ __forceinline__ float mish_grad(float x) {   // tanh(sp) + x * (1 - tanh(sp)^2) * sigmoid(x)
+    if (x > 20.f) return 1.f;
+    const float e = __expf(x), n = e * (e + 2.f), t = n / (n + 2.f);
+    return t + x * (1.f - t * t) * (e / (1.f + e));
+}
+
 __device__ __forceinline__ float view_load(const tr_view& v, int64_t pix, int c) {
     int64_t idx = pix * v.cstride + v.coff + c;
     if (v.dtype != TR_F32) return h_to_f32(((const unsigned short*)v.ptr)[idx], v.dtype);

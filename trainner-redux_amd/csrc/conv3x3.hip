@@ -41,7 +41,7 @@ struct ConvArgs {
     int replicate;
     int act;
     float slope, scale1, scale2, rs1, rs2, mask_slope, out2_scale;
-    int mask_mode;                 // 0: multiply by (m > 0 ? 1 : mask_slope) ; 1: multiply by gelu'(m)
+    int mask_mode;                 // 0: multiply by (m > 0 ? 1 : mask_slope) ; 1 / 2 / 3: multiply by gelu'(m) / silu'(m) / mish'(m)
     const float* sample_scale;     // optional n floats: v *= sample_scale[image] before the first residual (DropPath keep mask)
     tr_view in, out, out2, res1, res2, mask;
     const char* wpacked;
@@ -150,6 +150,9 @@ __device__ __forceinline__ float gelu_grad(float x) {   // d/dx [x * Phi(x)], ex
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
     return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
+__device__ __forceinline__ float act_pre_grad(int mode, float m) {   // mask_mode 1 / 2 / 3: derivative of GELU / SiLU / Mish at the pre-activation m
+    return mode == 1 ? gelu_grad(m) : mode == 2 ? silu_grad(m) : tr::mish_grad(m);
+}
 
 // ---- fused epilogue: bias, activation, two scaled residuals, derivative mask, dual-dtype NHWC stores ------------------
 // The MFMA accumulator holds, per lane, ONE pixel and 16 scattered channel quads, so storing from it directly issues
@@ -226,6 +229,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             } else if (a.act == TR_ACT_SILU) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.f + __expf(-v[k]));
+            } else if (a.act == TR_ACT_MISH) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = tr::mish(v[k]);
             }
             if (a.sample_scale) {
                 const float ss = a.sample_scale[nb];
@@ -249,6 +255,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                         v[0] *= gelu_grad(mm.x); v[1] *= gelu_grad(mm.y); v[2] *= gelu_grad(mm.z); v[3] *= gelu_grad(mm.w);
                     } else if (a.mask_mode == 2) {
                         v[0] *= silu_grad(mm.x); v[1] *= silu_grad(mm.y); v[2] *= silu_grad(mm.z); v[3] *= silu_grad(mm.w);
+                    } else if (a.mask_mode == 3) {
+                        v[0] *= tr::mish_grad(mm.x); v[1] *= tr::mish_grad(mm.y); v[2] *= tr::mish_grad(mm.z); v[3] *= tr::mish_grad(mm.w);
                     } else {
                         v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
                         v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
@@ -257,7 +265,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                 tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), true);
                 if (a.out2.ptr) {
                     const float sc = a.out2_scale;
-                    if (a.act == TR_ACT_GELU || a.act == TR_ACT_SILU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
+                    if (a.act >= TR_ACT_GELU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
                     else tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
                 }
             } else {
@@ -267,10 +275,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                     if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
                     if (a.mask.ptr) {
                         const float m = tr::view_load(a.mask, pix, co + k);
-                        x *= a.mask_mode == 1 ? gelu_grad(m) : a.mask_mode == 2 ? silu_grad(m) : (m > 0.f ? 1.f : a.mask_slope);
+                        x *= a.mask_mode ? act_pre_grad(a.mask_mode, m) : (m > 0.f ? 1.f : a.mask_slope);
                     }
                     tr::view_store(a.out, pix, co + k, x);
-                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, (a.act == TR_ACT_GELU || a.act == TR_ACT_SILU) ? pre[k] : x * a.out2_scale);
+                    if (a.out2.ptr) tr::view_store(a.out2, pix, co + k, a.act >= TR_ACT_GELU ? pre[k] : x * a.out2_scale);
                 }
             }
         }

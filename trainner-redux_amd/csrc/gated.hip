@@ -1,0 +1,315 @@
+// MoSR GatedCNNBlock pieces that are not dense contractions: depthwise k x k convolution (forward / input gradient / weight gradient),
+// the Mish gate and the Mish derivative sweep.  All of them are stencil / element-wise work on NHWC channel slices (HBM / VALU bound).
+// Contract: include/trainner_hip.h.  Reference arithmetic replaced (spandrel's MoSR is absent from /root/reference; the block is the
+// one of its in-tree twins):
+//   g, i, c = split(fc1(norm(x)))            traiNNer/archs/mosrv2_arch.py:121-122, moesr_arch.py:101-102
+//   c = conv(c)        (depthwise, MoSR v1: nn.Conv2d(cc, cc, k, 1, k // 2, groups=cc))
+//   act(g) * cat(i, c)                       mosrv2_arch.py:124, moesr_arch.py:104
+#include "common.h"
+
+namespace {
+
+constexpr int DW_TH = 16;      // output rows per workgroup strip
+constexpr int DW_TW = 32;      // output columns per workgroup
+constexpr int DW_CB = 32;      // channels per workgroup (8 lanes x 4)
+
+struct DwGeom {
+    int nstrips, ncolblk, ncb;
+    int64_t nsp;               // spatial workgroups: n * nstrips * ncolblk
+};
+inline DwGeom dw_geom(int n, int h, int w, int c) {
+    DwGeom g;
+    g.nstrips = (h + DW_TH - 1) / DW_TH;
+    g.ncolblk = (w + DW_TW - 1) / DW_TW;
+    g.ncb = (c + DW_CB - 1) / DW_CB;
+    g.nsp = (int64_t)n * g.nstrips * g.ncolblk;
+    return g;
+}
+
+__device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& v) {
+    a.x = fmaf(w.x, v.x, a.x); a.y = fmaf(w.y, v.y, a.y); a.z = fmaf(w.z, v.z, a.z); a.w = fmaf(w.w, v.w, a.w);
+}
+
+// One thread = one output column x one 4-channel quad, walking down a strip of DW_TH rows: for a fixed kx the K + DW_TH - 1 input values
+// of that column are loaded once each and feed up to K output rows from registers, so the kernel issues (K + TH - 1) * K loads for
+// TH * K * K float4 FMAs.  Lanes of a wave cover 8 columns x 32 contiguous channels (64 B of 16-bit data per pixel record).
+// Weights [c][K][K] (the OIHW tensor of a groups = c conv, I = 1) are staged per workgroup in LDS as [tap][channel]; `flip` mirrors
+// the taps, which turns the forward into the input gradient.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(tr_view in, tr_view out, const float* __restrict__ wt, const float* __restrict__ bias, int h, int w, int c,
+                                                      int flip, int nstrips, int ncolblk, int ncb, int vin, int vout) {
+    constexpr int P = K / 2;
+    __shared__ float wl[K * K][DW_CB];
+    int b = blockIdx.x;
+    const int cb = b % ncb; b /= ncb;
+    const int xb = b % ncolblk; b /= ncolblk;
+    const int sb = b % nstrips;
+    const int nb = b / nstrips;
+    for (int i = threadIdx.x; i < K * K * DW_CB; i += 256) {
+        const int ch = i % DW_CB, tap = i / DW_CB;
+        const int cc = cb * DW_CB + ch;
+        wl[tap][ch] = cc < c ? wt[(int64_t)cc * K * K + (flip ? K * K - 1 - tap : tap)] : 0.f;
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, col = threadIdx.x >> 3;
+    const int c0 = cb * DW_CB + q * 4;
+    const int ox = xb * DW_TW + col;
+    const int y0 = sb * DW_TH;
+    if (c0 >= c || ox >= w) return;
+    float4 acc[DW_TH];
+    {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = make_float4(bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]);
+#pragma unroll
+        for (int o = 0; o < DW_TH; ++o) acc[o] = b4;
+    }
+    const int64_t img = (int64_t)nb * h;
+    // kx stays a rolled loop: unrolled, the scheduler hoists all (K + TH - 1) * K loads to the top and spills
+#pragma unroll 1
+    for (int kx = 0; kx < K; ++kx) {
+        float4 wc[K];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) wc[ky] = *(const float4*)&wl[ky * K + kx][q * 4];
+        const int ix = ox + kx - P;
+        const bool xin = ix >= 0 && ix < w;
+#pragma unroll
+        for (int r = 0; r < DW_TH + K - 1; ++r) {
+            const int iy = y0 + r - P;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xin && iy >= 0 && iy < h) v = tr::view_load4(in, (img + iy) * w + ix, c0, vin);
+#pragma unroll
+            for (int o = 0; o < DW_TH; ++o) {
+                const int ky = r - o;
+                if (ky >= 0 && ky < K) fma4(acc[o], wc[ky], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < DW_TH; ++o) {
+        const int oy = y0 + o;
+        if (oy < h) tr::view_store4(out, (img + oy) * w + ox, c0, acc[o], vout);
+    }
+}
+
+// Weight gradient: dW[c][ky][kx] = sum_p gy[p][c] * x[p + (ky - P, kx - P)][c].  One workgroup = one (strip, kx): a thread keeps the
+// DW_TH gradient values of its column in registers, walks the K + TH - 1 input rows of the column shifted by kx - P and accumulates the K
+// vertical taps; the 32 columns of the workgroup are then summed through LDS in a fixed order and written as one partial row
+// [spatial workgroup][channel][K*K + 1] (the last slot is the bias gradient, produced by the centre-kx workgroups).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(tr_view in, tr_view gy, float* __restrict__ partials, int h, int w, int c, int nstrips, int ncolblk,
+                                                            int ncb, int vin, int vgy) {
+    constexpr int P = K / 2;
+    constexpr int NS = K * K + 1;
+    __shared__ float4 red[DW_TW][8][K + 1];
+    int b = blockIdx.x;
+    const int kx = b % K; b /= K;
+    const int cb = b % ncb; b /= ncb;
+    const int sp = b;                            // spatial workgroup index (image, strip, column block)
+    const int xb = b % ncolblk; b /= ncolblk;
+    const int sb = b % nstrips;
+    const int nb = b / nstrips;
+    const int q = threadIdx.x & 7, col = threadIdx.x >> 3;
+    const int c0 = cb * DW_CB + q * 4;
+    const int ox = xb * DW_TW + col;
+    const int y0 = sb * DW_TH;
+    const int64_t img = (int64_t)nb * h;
+    float4 aw[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < c && ox < w) {
+        float4 g[DW_TH];
+#pragma unroll
+        for (int o = 0; o < DW_TH; ++o) {
+            const int oy = y0 + o;
+            g[o] = oy < h ? tr::view_load4(gy, (img + oy) * w + ox, c0, vgy) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kx == P) { aw[K].x += g[o].x; aw[K].y += g[o].y; aw[K].z += g[o].z; aw[K].w += g[o].w; }
+        }
+        const int ix = ox + kx - P;
+        if (ix >= 0 && ix < w) {
+#pragma unroll
+            for (int r = 0; r < DW_TH + K - 1; ++r) {
+                const int iy = y0 + r - P;
+                if (iy < 0 || iy >= h) continue;
+                const float4 v = tr::view_load4(in, (img + iy) * w + ix, c0, vin);
+#pragma unroll
+                for (int o = 0; o < DW_TH; ++o) {
+                    const int ky = r - o;
+                    if (ky >= 0 && ky < K) fma4(aw[ky], g[o], v);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k <= K; ++k) red[col][q][k] = aw[k];
+    __syncthreads();
+    if (threadIdx.x < 8 * (K + 1)) {
+        const int qq = threadIdx.x & 7, k = threadIdx.x >> 3;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int cc = 0; cc < DW_TW; ++cc) {
+            const float4 t = red[cc][qq][k];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const int ch = cb * DW_CB + qq * 4;
+        if (ch < c && (k < K || kx == P)) {
+            const int slot = k < K ? k * K + kx : K * K;
+            float* dst = partials + ((int64_t)sp * c + ch) * NS + slot;
+            dst[0] = s.x; dst[NS] = s.y; dst[2 * NS] = s.z; dst[3 * NS] = s.w;
+        }
+    }
+}
+
+// dw[c][tap] (+)= sum over the spatial partial rows, in a fixed order: one wave per (channel, slot), lanes stride the rows and a
+// butterfly adds them (same pattern every run, so the result is bitwise reproducible).
+__global__ __launch_bounds__(256) void dwconv_wgrad_finish_kernel(const float* __restrict__ partials, int64_t nsp, int c, int ns, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int accumulate) {
+    const int l = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= c * ns) return;
+    const int ch = item / ns, slot = item - ch * ns;
+    float s = 0.f;
+    for (int64_t r = l; r < nsp; r += 64) s += partials[(r * c + ch) * ns + slot];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (l == 0) {
+        if (slot < ns - 1) {
+            float* d = dw + (int64_t)ch * (ns - 1) + slot;
+            *d = accumulate ? *d + s : s;
+        } else if (db) {
+            db[ch] = accumulate ? db[ch] + s : s;
+        }
+    }
+}
+
+// ---- Mish gate: out[p][j] = mish(g[p][j]) * u[p][j], u = cat(a, b) along channels ------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_mish_kernel(tr_view g, tr_view a, tr_view b, tr_view out, int64_t npix, int c4, int ca, int vg, int va, int vb,
+                                                         int vo) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int ch = (int)(i - p * c4) * 4;
+        const float4 gg = tr::view_load4(g, p, ch, vg);
+        const float4 u = ch < ca ? tr::view_load4(a, p, ch, va) : tr::view_load4(b, p, ch - ca, vb);
+        tr::view_store4(out, p, ch, make_float4(tr::mish(gg.x) * u.x, tr::mish(gg.y) * u.y, tr::mish(gg.z) * u.z, tr::mish(gg.w) * u.w), vo);
+    }
+}
+
+// given d = d/d(out): dg = d * u * mish'(g) ; du = d * mish(g), written to the a / b parts of the gradient views
+__global__ __launch_bounds__(256) void gate_mish_bwd_kernel(tr_view d, tr_view g, tr_view a, tr_view b, tr_view dg, tr_view da, tr_view db, int64_t npix,
+                                                             int c4, int ca, int vd, int vg, int va, int vb, int vdg, int vda, int vdb) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int ch = (int)(i - p * c4) * 4;
+        const float4 dd = tr::view_load4(d, p, ch, vd), gg = tr::view_load4(g, p, ch, vg);
+        const float4 u = ch < ca ? tr::view_load4(a, p, ch, va) : tr::view_load4(b, p, ch - ca, vb);
+        const float4 r = make_float4(dd.x * u.x * tr::mish_grad(gg.x), dd.y * u.y * tr::mish_grad(gg.y), dd.z * u.z * tr::mish_grad(gg.z),
+                                     dd.w * u.w * tr::mish_grad(gg.w));
+        const float4 s = make_float4(dd.x * tr::mish(gg.x), dd.y * tr::mish(gg.y), dd.z * tr::mish(gg.z), dd.w * tr::mish(gg.w));
+        tr::view_store4(dg, p, ch, r, vdg);
+        if (ch < ca) tr::view_store4(da, p, ch, s, vda);
+        else tr::view_store4(db, p, ch - ca, s, vdb);
+    }
+}
+
+// out = g * s[p / pix_per_sample] * act'(pre)
+__global__ __launch_bounds__(256) void act_grad_kernel(tr_view g, tr_view pre, tr_view out, int act, int64_t npix, int c4, int vg, int vp, int vo,
+                                                        const float* __restrict__ sscale, int64_t pps) {
+    const int64_t total = npix * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / c4;
+        const int ch = (int)(i - p * c4) * 4;
+        const float4 gg = tr::view_load4(g, p, ch, vg), m = tr::view_load4(pre, p, ch, vp);
+        float mv[4] = {m.x, m.y, m.z, m.w}, d[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (act == TR_ACT_MISH) d[k] = tr::mish_grad(mv[k]);
+            else {   // TR_ACT_SILU
+                const float sg = 1.f / (1.f + __expf(-mv[k]));
+                d[k] = sg * (1.f + mv[k] * (1.f - sg));
+            }
+        }
+        const float ss = sscale ? sscale[p / pps] : 1.f;
+        tr::view_store4(out, p, ch, make_float4(gg.x * ss * d[0], gg.y * ss * d[1], gg.z * ss * d[2], gg.w * ss * d[3]), vo);
+    }
+}
+
+inline bool view_has(const tr_view& v, int c) { return v.ptr && v.c >= c && v.coff >= 0 && v.coff + c <= v.cstride; }
+
+inline unsigned sweep_grid(int64_t items) {
+    int64_t b = (items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int tr_dwconv(void* stream, tr_view in, tr_view out, const float* weight, const float* bias, int n, int h, int w, int c, int ksize, int flip) {
+    TR_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, TR_EINVAL, "tr_dwconv: bad dims n=%d h=%d w=%d c=%d (c must be a multiple of 4)", n, h, w, c);
+    TR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, TR_EUNSUPPORTED, "tr_dwconv: kernel size %d is not built (3, 5, 7)", ksize);
+    TR_REQUIRE(view_has(in, c) && view_has(out, c) && weight, TR_EINVAL, "tr_dwconv: in / out views must hold c=%d channels and weight must be set", c);
+    const DwGeom g = dw_geom(n, h, w, c);
+    TR_REQUIRE(g.nsp * g.ncb < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_dwconv: grid too large");
+    const dim3 grid((unsigned)(g.nsp * g.ncb));
+    hipStream_t st = (hipStream_t)stream;
+    const int vin = tr::view_vec4_ok(in), vout = tr::view_vec4_ok(out);
+#define TR_DW(K) hipLaunchKernelGGL(dwconv_kernel<K>, grid, dim3(256), 0, st, in, out, weight, bias, h, w, c, flip ? 1 : 0, g.nstrips, g.ncolblk, g.ncb, vin, vout)
+    if (ksize == 7) TR_DW(7); else if (ksize == 5) TR_DW(5); else TR_DW(3);
+#undef TR_DW
+    return tr::launch_status("tr_dwconv");
+}
+
+extern "C" size_t tr_dwconv_wgrad_workspace_bytes(int n, int h, int w, int c, int ksize) {
+    const DwGeom g = dw_geom(n, h, w, c);
+    return (size_t)g.nsp * c * (ksize * ksize + 1) * sizeof(float);
+}
+
+extern "C" int tr_dwconv_wgrad(void* stream, tr_view in, tr_view gy, float* dw, float* db, int n, int h, int w, int c, int ksize, int accumulate,
+                               float* partials, size_t partials_bytes) {
+    TR_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, TR_EINVAL, "tr_dwconv_wgrad: bad dims n=%d h=%d w=%d c=%d", n, h, w, c);
+    TR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, TR_EUNSUPPORTED, "tr_dwconv_wgrad: kernel size %d is not built (3, 5, 7)", ksize);
+    TR_REQUIRE(view_has(in, c) && view_has(gy, c) && dw && partials, TR_EINVAL, "tr_dwconv_wgrad: in / gy views must hold c=%d channels; dw and partials must be set", c);
+    const size_t need = tr_dwconv_wgrad_workspace_bytes(n, h, w, c, ksize);
+    TR_REQUIRE(partials_bytes >= need, TR_EINVAL, "tr_dwconv_wgrad: workspace too small (need %zu bytes)", need);
+    const DwGeom g = dw_geom(n, h, w, c);
+    TR_REQUIRE(g.nsp * g.ncb * ksize < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_dwconv_wgrad: grid too large");
+    const dim3 grid((unsigned)(g.nsp * g.ncb * ksize));
+    hipStream_t st = (hipStream_t)stream;
+    const int vin = tr::view_vec4_ok(in), vgy = tr::view_vec4_ok(gy);
+#define TR_DWG(K) hipLaunchKernelGGL(dwconv_wgrad_kernel<K>, grid, dim3(256), 0, st, in, gy, partials, h, w, c, g.nstrips, g.ncolblk, g.ncb, vin, vgy)
+    if (ksize == 7) TR_DWG(7); else if (ksize == 5) TR_DWG(5); else TR_DWG(3);
+#undef TR_DWG
+    const int ns = ksize * ksize + 1;
+    hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((unsigned)((c * ns + 3) / 4)), dim3(256), 0, st, partials, g.nsp, c, ns, dw, db, accumulate ? 1 : 0);
+    return tr::launch_status("tr_dwconv_wgrad");
+}
+
+extern "C" int tr_gate_mish(void* stream, tr_view g, tr_view a, tr_view b, tr_view out, int64_t npix) {
+    TR_REQUIRE(g.ptr && a.ptr && b.ptr && out.ptr && npix > 0, TR_EINVAL, "tr_gate_mish: views must be set");
+    TR_REQUIRE(g.c == a.c + b.c && out.c == g.c && g.c % 4 == 0 && a.c % 4 == 0, TR_EINVAL,
+               "tr_gate_mish: channel counts g=%d a=%d b=%d out=%d (g = a + b = out, multiples of 4)", g.c, a.c, b.c, out.c);
+    const int c4 = g.c / 4;
+    hipLaunchKernelGGL(gate_mish_kernel, dim3(sweep_grid(npix * c4)), dim3(256), 0, (hipStream_t)stream, g, a, b, out, npix, c4, a.c, tr::view_vec4_ok(g),
+                       tr::view_vec4_ok(a), tr::view_vec4_ok(b), tr::view_vec4_ok(out));
+    return tr::launch_status("tr_gate_mish");
+}
+
+extern "C" int tr_gate_mish_bwd(void* stream, tr_view d, tr_view g, tr_view a, tr_view b, tr_view dg, tr_view da, tr_view db, int64_t npix) {
+    TR_REQUIRE(d.ptr && g.ptr && a.ptr && b.ptr && dg.ptr && da.ptr && db.ptr && npix > 0, TR_EINVAL, "tr_gate_mish_bwd: views must be set");
+    TR_REQUIRE(g.c == a.c + b.c && d.c == g.c && dg.c == g.c && da.c == a.c && db.c == b.c && g.c % 4 == 0 && a.c % 4 == 0, TR_EINVAL,
+               "tr_gate_mish_bwd: channel counts do not fit (g=%d a=%d b=%d)", g.c, a.c, b.c);
+    const int c4 = g.c / 4;
+    hipLaunchKernelGGL(gate_mish_bwd_kernel, dim3(sweep_grid(npix * c4)), dim3(256), 0, (hipStream_t)stream, d, g, a, b, dg, da, db, npix, c4, a.c,
+                       tr::view_vec4_ok(d), tr::view_vec4_ok(g), tr::view_vec4_ok(a), tr::view_vec4_ok(b), tr::view_vec4_ok(dg), tr::view_vec4_ok(da),
+                       tr::view_vec4_ok(db));
+    return tr::launch_status("tr_gate_mish_bwd");
+}
+
+extern "C" int tr_act_grad(void* stream, int act, tr_view g, tr_view pre, tr_view out, int64_t npix, const float* sample_scale, int64_t pix_per_sample) {
+    TR_REQUIRE(!sample_scale || pix_per_sample > 0, TR_EINVAL, "tr_act_grad: a per-sample scale needs pix_per_sample > 0");
+    TR_REQUIRE(g.ptr && pre.ptr && out.ptr && npix > 0, TR_EINVAL, "tr_act_grad: views must be set");
+    TR_REQUIRE(act == TR_ACT_MISH || act == TR_ACT_SILU, TR_EUNSUPPORTED, "tr_act_grad: activation %d is not built (SiLU, Mish)", act);
+    TR_REQUIRE(g.c == pre.c && out.c == g.c && g.c % 4 == 0, TR_EINVAL, "tr_act_grad: channel counts g=%d pre=%d out=%d", g.c, pre.c, out.c);
+    const int c4 = g.c / 4;
+    hipLaunchKernelGGL(act_grad_kernel, dim3(sweep_grid(npix * c4)), dim3(256), 0, (hipStream_t)stream, g, pre, out, act, npix, c4, tr::view_vec4_ok(g),
+                       tr::view_vec4_ok(pre), tr::view_vec4_ok(out), sample_scale, pix_per_sample > 0 ? pix_per_sample : 1);
+    return tr::launch_status("tr_act_grad");
+}

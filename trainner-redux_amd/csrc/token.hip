@@ -27,16 +27,24 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int LN_MAXK = 12;   // C <= 768
 constexpr int LN_BWD_BLOCKS = 1024;
 
+template <int NK>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(tr_view x, tr_view y, int64_t ntok, int c, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, float* __restrict__ mean_out,
                                                              float* __restrict__ rstd_out) {
     const int l = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    float gm[NK], bt[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int ch = l + 64 * k;
+        gm[k] = ch < c ? gamma[ch] : 0.f;
+        bt[k] = ch < c ? beta[ch] : 0.f;
+    }
     for (int64_t t = wave; t < ntok; t += nwaves) {
-        float v[LN_MAXK];
+        float v[NK];
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int ch = l + 64 * k;
             v[k] = ch < c ? tr::view_load(x, t, ch) : 0.f;
             s += v[k];
@@ -44,16 +52,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(tr_view x, tr_view y
         const float mean = wave_sum(s) / (float)c;
         float q = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int ch = l + 64 * k;
             const float d = ch < c ? v[k] - mean : 0.f;
             q += d * d;
         }
         const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
 #pragma unroll
-        for (int k = 0; k < LN_MAXK; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int ch = l + 64 * k;
-            if (ch < y.c) tr::view_store(y, t, ch, ch < c ? (v[k] - mean) * rstd * gamma[ch] + beta[ch] : 0.f);
+            if (ch < y.c) tr::view_store(y, t, ch, ch < c ? (v[k] - mean) * rstd * gm[k] + bt[k] : 0.f);
         }
         if (l == 0 && mean_out) { mean_out[t] = mean; rstd_out[t] = rstd; }
     }
@@ -361,8 +369,13 @@ extern "C" int tr_layernorm(void* stream, tr_view x, tr_view y, int64_t ntok, in
     TR_REQUIRE(x.ptr && y.ptr && gamma && beta && ntok > 0 && c > 0 && c <= LN_MAXK * 64 && x.c >= c && y.c >= c && y.c <= LN_MAXK * 64, TR_EINVAL,
                "tr_layernorm: bad arguments (c <= %d)", LN_MAXK * 64);
     TR_REQUIRE((mean_out == nullptr) == (rstd_out == nullptr), TR_EINVAL, "tr_layernorm: mean/rstd outputs come together");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(ntok * 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, y, ntok, c, gamma, beta, eps, mean_out,
-                       rstd_out);
+    const int nk = (y.c + 63) / 64;         // the store loop covers the padded width of y
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(grid_for(ntok * 64, 2048));
+#define TR_LN_FWD(NK) hipLaunchKernelGGL(layernorm_fwd_kernel<NK>, grid, dim3(256), 0, st, x, y, ntok, c, gamma, beta, eps, mean_out, rstd_out)
+    if (nk <= 1) TR_LN_FWD(1); else if (nk <= 2) TR_LN_FWD(2); else if (nk <= 3) TR_LN_FWD(3); else if (nk <= 4) TR_LN_FWD(4);
+    else if (nk <= 6) TR_LN_FWD(6); else if (nk <= 8) TR_LN_FWD(8); else TR_LN_FWD(12);
+#undef TR_LN_FWD
     return tr::launch_status("tr_layernorm");
 }
 
@@ -370,7 +383,9 @@ extern "C" int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok
                                 tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes) {
     TR_REQUIRE(g.ptr && x.ptr && dx.ptr && gamma && mean && rstd && dgamma && dbeta && partials && ntok > 0 && c > 0 && c <= LN_MAXK * 64, TR_EINVAL,
                "tr_layernorm_bwd: bad arguments");
-    int nb = (int)grid_for(ntok * 32, LN_BWD_BLOCKS);      // a wave takes two tokens per iteration
+    // a wave takes two tokens per iteration; at least 8 iterations per wave so that the partial rows (one per block, summed by the
+    // finish kernel) stay few when the token count is small
+    int nb = (int)grid_for(ntok * 4, LN_BWD_BLOCKS);
     TR_REQUIRE(partials_bytes >= (size_t)nb * 2 * c * sizeof(float), TR_EINVAL, "tr_layernorm_bwd: workspace too small (need %zu bytes)",
                (size_t)nb * 2 * c * sizeof(float));
     hipStream_t st = (hipStream_t)stream;

@@ -259,6 +259,36 @@ def span_gate_bwd(g: L.View, o3: L.View, x: L.View, g_o3: L.View, g_x: L.View | 
             "tr_span_gate_bwd")
 
 
+def dwconv(inp: L.View, out: L.View, weight: torch.Tensor, bias: torch.Tensor | None, n, h, w, c, flip: bool = False):
+    """Depthwise k x k conv (groups = c) on NHWC channel slices; flip = the input gradient of the same conv."""
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[0] == c and weight.shape[1] == 1 and weight.shape[2] == weight.shape[3]
+    L.check(L.lib().tr_dwconv(stream_ptr(), inp, out, weight.data_ptr(), bias.data_ptr() if bias is not None else None, n, h, w, c, weight.shape[2],
+                              1 if flip else 0), "tr_dwconv")
+
+
+def dwconv_wgrad_workspace_bytes(n, h, w, c, ksize) -> int:
+    return int(L.lib().tr_dwconv_wgrad_workspace_bytes(n, h, w, c, ksize))
+
+
+def dwconv_wgrad(inp: L.View, gy: L.View, dw: torch.Tensor, db: torch.Tensor | None, n, h, w, c, workspace: torch.Tensor, accumulate=True):
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.shape[0] == c and dw.shape[1] == 1 and dw.shape[2] == dw.shape[3]
+    L.check(L.lib().tr_dwconv_wgrad(stream_ptr(), inp, gy, dw.data_ptr(), db.data_ptr() if db is not None else None, n, h, w, c, dw.shape[2],
+                                    1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size()), "tr_dwconv_wgrad")
+
+
+def gate_mish(g: L.View, a: L.View, b: L.View, out: L.View, npix: int):
+    L.check(L.lib().tr_gate_mish(stream_ptr(), g, a, b, out, npix), "tr_gate_mish")
+
+
+def gate_mish_bwd(d: L.View, g: L.View, a: L.View, b: L.View, dg: L.View, da: L.View, db: L.View, npix: int):
+    L.check(L.lib().tr_gate_mish_bwd(stream_ptr(), d, g, a, b, dg, da, db, npix), "tr_gate_mish_bwd")
+
+
+def act_grad(act: int, g: L.View, pre: L.View, out: L.View, npix: int, sample_scale: torch.Tensor | None = None, pix_per_sample: int = 0):
+    L.check(L.lib().tr_act_grad(stream_ptr(), act, g, pre, out, npix, sample_scale.data_ptr() if sample_scale is not None else None, pix_per_sample),
+            "tr_act_grad")
+
+
 def space_to_depth2(inp: L.View, out: L.View, n, h, w):
     L.check(L.lib().tr_space_to_depth2(stream_ptr(), inp, out, n, h, w), "tr_space_to_depth2")
 
