@@ -34,9 +34,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s", "span", "span_s"],
+    ap.add_argument("--arch", default="esrgan", choices=["esrgan", "swinir_m", "swinir_s", "span", "span_s", "mosr", "mosr_t"],
                     help="esrgan = BASELINE.json configs[1] (the default bench line); swinir_* = configs[3] (64->256 tiles); "
-                         "span* = configs[4] (2x, batch 64 per GPU; add --compute f16 for its fp16 + loss-scaling mode)")
+                         "span* / mosr* = configs[4] (2x, batch 64 per GPU; add --compute f16 for its fp16 + loss-scaling mode)")
     ap.add_argument("--scale", type=int, default=None, help="default 4 (2 for span)")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 16 for esrgan = configs[1], 8 for swinir = configs[3] / SURVEY.md cfg4)")
     ap.add_argument("--lq", type=int, default=None, help="LR tile size (default 256 for esrgan, 64 for swinir)")
@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     swin = args.arch != "esrgan"
-    span = args.arch.startswith("span")
+    span = args.arch.startswith("span") or args.arch.startswith("mosr")     # the configs[4] shape
     args.scale = args.scale or (2 if span else 4)
     args.batch = args.batch or (64 if span else 8 if swin else 16)
     args.lq = args.lq or (64 if swin else 256)
@@ -158,6 +158,12 @@ def cpu_baseline(args, perceptual: bool):
         g0 = torch.Generator().manual_seed(0)
         sd = OrderedDict((k, torch.randn(shp, generator=g0) * 0.05) for k, shp in OSP.param_table(hp).items() if "eval_conv" not in k)
         fwd = lambda p, x: OSP.forward(p, x, hp)  # noqa: E731
+    elif args.arch.startswith("mosr"):
+        from oracle import mosr as OM
+
+        hp = OM.hparams(scale=args.scale, **OM.PRESETS[args.arch])
+        sd = OM.init_params(hp, 0)
+        fwd = lambda p, x: OM.forward(p, x, hp)  # noqa: E731
     else:
         hp = OW.hparams(args.arch, scale=4)
         sd = OW.init_state_dict(hp, 0)
@@ -257,7 +263,7 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            "metric": f"training images/sec ({s}->{sc * s} {sc}x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SPAN" if args.arch.startswith("span") else "SwinIR"),
+            "metric": f"training images/sec ({s}->{sc * s} {sc}x SR) " + ("ESRGAN" if args.arch == "esrgan" else "SPAN" if args.arch.startswith("span") else "MoSR" if args.arch.startswith("mosr") else "SwinIR"),
             "value": n * world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",

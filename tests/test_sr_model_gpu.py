@@ -262,3 +262,28 @@ def test_span_step_matches_oracle(cuda):
     e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in train.items())
     print("span weights after one step", e_w)
     assert e_w < 5e-4
+
+
+def test_mosr_step_matches_oracle(cuda):
+    """MoSR generator behind the trainer (`mosr_t` shape, 4x): one L1 step in fp32 against the oracle's step."""
+    from oracle import losses as OL, mosr as OM, step as OS
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], network_g=dict(type="mosr_t", n_block=2, dim=32))
+    model = SRModel(opt)
+    hp = OM.hparams(scale=4, n_block=2, dim=32)
+    sd = {k: v.detach().cpu().clone() for k, v in model.net_g.state_dict().items()}
+    assert list(sd) == list(OM.param_table(hp))
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    lq, gt = _data(seed=5)
+    _, ld, _, _ = OS.generator_step(params, lambda p, x: OM.forward(p, x, hp), OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, None)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 1e-5 * float(ld["l_g_l1"])
+    assert abs(log["grad_norm_g"] - float(ld["grad_norm_g"])) < 1e-4 * float(ld["grad_norm_g"])
+    sdm = model.net_g.state_dict()
+    e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in params.items())
+    print("mosr weights after one step", e_w)
+    assert e_w < 5e-4

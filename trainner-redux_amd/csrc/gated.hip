@@ -30,15 +30,48 @@ __device__ __forceinline__ void fma4(float4& a, const float4& w, const float4& v
     a.x = fmaf(w.x, v.x, a.x); a.y = fmaf(w.y, v.y, a.y); a.z = fmaf(w.z, v.z, a.z); a.w = fmaf(w.w, v.w, a.w);
 }
 
+// Branch-free operand fetch: the raw 4-channel load is issued unconditionally (from a clamped address) so that a whole column of loads
+// is in flight at once; tr::view_load4 switches on the runtime dtype, which serialises every load behind the previous one's use
+// (measured: 149 us instead of 40 for 64 channels at 64 x 64 x 64).  H16 = the view holds bf16 / fp16 (8-byte loads), else fp32.
+template <bool H16> struct Raw4 { typedef float4 T; };
+template <> struct Raw4<true> { typedef uint2 T; };
+// Addressing: a uniform 64-bit image base (scalar registers) plus a 32-bit byte offset per lane = uniform row offset + the lane's column
+// offset, i.e. one 32-bit add per load.  (Indexing through 64-bit pixel numbers cost four quarter-rate integer multiplies per load:
+// 570 of them against 1568 packed FMAs in the 7 x 7 kernel.)  One image of a view must therefore stay below 2 GiB.
+template <bool H16>
+__device__ __forceinline__ const char* image_base(const tr_view& v, int64_t nb, int h, int w) {
+    return (const char*)v.ptr + ((int64_t)nb * h * w * v.cstride + v.coff) * (H16 ? 2 : 4);
+}
+template <bool H16>
+__device__ __forceinline__ typename Raw4<H16>::T raw_load4(const char* base, uint32_t off) {
+    return *(const typename Raw4<H16>::T*)(base + off);
+}
+__device__ __forceinline__ float4 raw_cvt4(const float4& r, int, bool valid) { return valid ? r : make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 raw_cvt4(const uint2& u, int dtype, bool valid) {
+    float4 r;
+    if (dtype == TR_BF16) {
+        r.x = __uint_as_float(u.x << 16); r.y = __uint_as_float(u.x & 0xffff0000u);
+        r.z = __uint_as_float(u.y << 16); r.w = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+        r.x = tr::f16_to_f32(u.x & 0xffffu); r.y = tr::f16_to_f32(u.x >> 16); r.z = tr::f16_to_f32(u.y & 0xffffu); r.w = tr::f16_to_f32(u.y >> 16);
+    }
+    return valid ? r : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // One thread = one output column x one 4-channel quad, walking down a strip of DW_TH rows: for a fixed kx the K + DW_TH - 1 input values
 // of that column are loaded once each and feed up to K output rows from registers, so the kernel issues (K + TH - 1) * K loads for
 // TH * K * K float4 FMAs.  Lanes of a wave cover 8 columns x 32 contiguous channels (64 B of 16-bit data per pixel record).
 // Weights [c][K][K] (the OIHW tensor of a groups = c conv, I = 1) are staged per workgroup in LDS as [tap][channel]; `flip` mirrors
-// the taps, which turns the forward into the input gradient.
-template <int K>
+// the taps, which turns the forward into the input gradient.  The column of the NEXT kx is in flight while the current one is
+// consumed (16-bit views: two register stages; fp32 views have no room for the second stage).  Padding: out-of-range columns zero the
+// kx weights of that lane, out-of-range rows (uniform per workgroup) skip their FMAs -- no per-load selects.
+template <int K, bool H16>
 __global__ __launch_bounds__(256) void dwconv_kernel(tr_view in, tr_view out, const float* __restrict__ wt, const float* __restrict__ bias, int h, int w, int c,
                                                       int flip, int nstrips, int ncolblk, int ncb, int vin, int vout) {
     constexpr int P = K / 2;
+    constexpr int NR = DW_TH + K - 1;
+    constexpr int NST = H16 ? 2 : 1;
+    typedef typename Raw4<H16>::T RT;
     __shared__ float wl[K * K][DW_CB];
     int b = blockIdx.x;
     const int cb = b % ncb; b /= ncb;
@@ -64,24 +97,51 @@ __global__ __launch_bounds__(256) void dwconv_kernel(tr_view in, tr_view out, co
         for (int o = 0; o < DW_TH; ++o) acc[o] = b4;
     }
     const int64_t img = (int64_t)nb * h;
-    // kx stays a rolled loop: unrolled, the scheduler hoists all (K + TH - 1) * K loads to the top and spills
-#pragma unroll 1
-    for (int kx = 0; kx < K; ++kx) {
-        float4 wc[K];
+    constexpr uint32_t ES = H16 ? 2 : 4;
+    const char* ibase = image_base<H16>(in, nb, h, w);
+    const uint32_t rowpitch = (uint32_t)w * in.cstride * ES;
+    RT raw[NST][NR];
+    auto fetch = [&](int kx, RT (&dst)[NR]) {
+        const uint32_t coloff = ((uint32_t)min(max(ox + kx - P, 0), w - 1) * in.cstride + c0) * ES;
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) wc[ky] = *(const float4*)&wl[ky * K + kx][q * 4];
+        for (int r = 0; r < NR; ++r) dst[r] = raw_load4<H16>(ibase, (uint32_t)min(max(y0 + r - P, 0), h - 1) * rowpitch + coloff);
+    };
+    auto consume = [&](int kx, const RT (&src)[NR]) {
         const int ix = ox + kx - P;
         const bool xin = ix >= 0 && ix < w;
+        float4 wc[K];
 #pragma unroll
-        for (int r = 0; r < DW_TH + K - 1; ++r) {
+        for (int ky = 0; ky < K; ++ky) {
+            wc[ky] = *(const float4*)&wl[ky * K + kx][q * 4];
+            if (!xin) wc[ky] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
             const int iy = y0 + r - P;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xin && iy >= 0 && iy < h) v = tr::view_load4(in, (img + iy) * w + ix, c0, vin);
+            if (iy < 0 || iy >= h) continue;          // uniform over the workgroup
+            const float4 v = raw_cvt4(src[r], in.dtype, true);
 #pragma unroll
             for (int o = 0; o < DW_TH; ++o) {
                 const int ky = r - o;
                 if (ky >= 0 && ky < K) fma4(acc[o], wc[ky], v);
             }
+        }
+    };
+    if constexpr (H16) {
+        fetch(0, raw[0]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            if (kx + 1 < K) fetch(kx + 1, raw[(kx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kx, raw[kx & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        // kx stays a rolled loop: unrolled, the scheduler hoists all NR * K loads to the top and spills
+#pragma unroll 1
+        for (int kx = 0; kx < K; ++kx) {
+            fetch(kx, raw[0]);
+            consume(kx, raw[0]);
         }
     }
 #pragma unroll
@@ -91,66 +151,133 @@ __global__ __launch_bounds__(256) void dwconv_kernel(tr_view in, tr_view out, co
     }
 }
 
-// Weight gradient: dW[c][ky][kx] = sum_p gy[p][c] * x[p + (ky - P, kx - P)][c].  One workgroup = one (strip, kx): a thread keeps the
-// DW_TH gradient values of its column in registers, walks the K + TH - 1 input rows of the column shifted by kx - P and accumulates the K
-// vertical taps; the 32 columns of the workgroup are then summed through LDS in a fixed order and written as one partial row
-// [spatial workgroup][channel][K*K + 1] (the last slot is the bias gradient, produced by the centre-kx workgroups).
-template <int K>
+// Weight gradient: dW[c][ky][kx] = sum_p gy[p][c] * x[p + (ky - P, kx - P)][c].  A thread keeps the DW_TH gradient values of its
+// (column, quad) in registers and, for each kx in turn, walks the K + TH - 1 input rows of the column shifted by kx - P accumulating the K
+// vertical taps (the next kx's column is in flight meanwhile).  After each kx the 8 columns of a wave are summed through a private LDS
+// strip by 56 of its lanes (fixed order), which keep the (quad, ky) sums of all kx in registers; at the end the 4 waves are added and the
+// workgroup writes ONE partial row [spatial workgroup][channel][K*K + 1] (last slot: bias gradient).
+template <int K, bool H16>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(tr_view in, tr_view gy, float* __restrict__ partials, int h, int w, int c, int nstrips, int ncolblk,
                                                             int ncb, int vin, int vgy) {
     constexpr int P = K / 2;
     constexpr int NS = K * K + 1;
-    __shared__ float4 red[DW_TW][8][K + 1];
+    constexpr int NR = DW_TH + K - 1;
+    constexpr int NST = H16 ? 2 : 1;
+    typedef typename Raw4<H16>::T RT;
+    __shared__ float4 strip[4][8][K + 1][8];          // [wave][quad][ky (+ bias)][column of the wave]
+    __shared__ float4 wsuml[4][8 * (K + 1)][K];       // [wave][(quad, ky)][kx]
     int b = blockIdx.x;
-    const int kx = b % K; b /= K;
     const int cb = b % ncb; b /= ncb;
     const int sp = b;                            // spatial workgroup index (image, strip, column block)
     const int xb = b % ncolblk; b /= ncolblk;
     const int sb = b % nstrips;
     const int nb = b / nstrips;
     const int q = threadIdx.x & 7, col = threadIdx.x >> 3;
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, wcol = l >> 3;
     const int c0 = cb * DW_CB + q * 4;
     const int ox = xb * DW_TW + col;
     const int y0 = sb * DW_TH;
     const int64_t img = (int64_t)nb * h;
-    float4 aw[K + 1];
+    const bool active = c0 < c && ox < w;
+    const int oxc = min(ox, w - 1), c0c = active ? c0 : 0;
+    (void)img;
+    float4 g[DW_TH];
+    float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr uint32_t ES = H16 ? 2 : 4;
+    const char* ibase = image_base<H16>(in, nb, h, w);
+    const char* gbase = image_base<H16>(gy, nb, h, w);
+    const uint32_t rowpitch = (uint32_t)w * in.cstride * ES, growpitch = (uint32_t)w * gy.cstride * ES;
+    {
+        RT graw[DW_TH];
+        const uint32_t gcol = ((uint32_t)oxc * gy.cstride + c0c) * ES;
 #pragma unroll
-    for (int k = 0; k <= K; ++k) aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c0 < c && ox < w) {
-        float4 g[DW_TH];
+        for (int o = 0; o < DW_TH; ++o) graw[o] = raw_load4<H16>(gbase, (uint32_t)min(y0 + o, h - 1) * growpitch + gcol);
 #pragma unroll
         for (int o = 0; o < DW_TH; ++o) {
-            const int oy = y0 + o;
-            g[o] = oy < h ? tr::view_load4(gy, (img + oy) * w + ox, c0, vgy) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kx == P) { aw[K].x += g[o].x; aw[K].y += g[o].y; aw[K].z += g[o].z; aw[K].w += g[o].w; }
-        }
-        const int ix = ox + kx - P;
-        if (ix >= 0 && ix < w) {
-#pragma unroll
-            for (int r = 0; r < DW_TH + K - 1; ++r) {
-                const int iy = y0 + r - P;
-                if (iy < 0 || iy >= h) continue;
-                const float4 v = tr::view_load4(in, (img + iy) * w + ix, c0, vin);
-#pragma unroll
-                for (int o = 0; o < DW_TH; ++o) {
-                    const int ky = r - o;
-                    if (ky >= 0 && ky < K) fma4(aw[ky], g[o], v);
-                }
-            }
+            g[o] = raw_cvt4(graw[o], gy.dtype, active && y0 + o < h);
+            gsum.x += g[o].x; gsum.y += g[o].y; gsum.z += g[o].z; gsum.w += g[o].w;
         }
     }
+    RT raw[NST][NR];
+    auto fetch = [&](int kx, RT (&dst)[NR]) {
+        const uint32_t coloff = ((uint32_t)min(max(ox + kx - P, 0), w - 1) * in.cstride + c0c) * ES;
 #pragma unroll
-    for (int k = 0; k <= K; ++k) red[col][q][k] = aw[k];
+        for (int r = 0; r < NR; ++r) dst[r] = raw_load4<H16>(ibase, (uint32_t)min(max(y0 + r - P, 0), h - 1) * rowpitch + coloff);
+    };
+    float4 wsum[K];                              // lanes < 8 * (K + 1): sums over the wave's 8 columns for (quad = l & 7, ky = l >> 3), per kx
+    auto consume = [&](int kx, const RT (&src)[NR]) {
+        const int ix = ox + kx - P;
+        const bool xin = active && ix >= 0 && ix < w;
+        float4 aw[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) aw[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int iy = y0 + r - P;
+            if (iy < 0 || iy >= h) continue;          // uniform over the workgroup
+            const float4 v = raw_cvt4(src[r], in.dtype, true);
+#pragma unroll
+            for (int o = 0; o < DW_TH; ++o) {
+                const int ky = r - o;
+                if (ky >= 0 && ky < K) fma4(aw[ky], g[o], v);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) strip[wv][q][k][wcol] = xin ? aw[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kx == P) strip[wv][q][K][wcol] = gsum;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (l < 8 * (K + 1)) {
+            const int qq = l & 7, k = l >> 3;
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K || kx == P) {
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    const float4 t = strip[wv][qq][k][cc];
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+            }
+            wsum[kx] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    if constexpr (H16) {
+        fetch(0, raw[0]);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            if (kx + 1 < K) fetch(kx + 1, raw[(kx + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kx, raw[kx & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            fetch(kx, raw[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(kx, raw[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (l < 8 * (K + 1)) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) wsuml[wv][l][kx] = wsum[kx];
+    }
     __syncthreads();
-    if (threadIdx.x < 8 * (K + 1)) {
-        const int qq = threadIdx.x & 7, k = threadIdx.x >> 3;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int cc = 0; cc < DW_TW; ++cc) {
-            const float4 t = red[cc][qq][k];
+    // 8 quads x (K taps + bias) x K kx items; item (qq, k, kx): k < K -> slot k * K + kx ; k == K -> bias slot (kx == P only)
+    for (int it = threadIdx.x; it < 8 * (K + 1) * K; it += 256) {
+        const int kx = it % K, lk = it / K;
+        const int qq = lk & 7, k = lk >> 3;
+        if (k == K && kx != P) continue;
+        float4 s = wsuml[0][lk][kx];
+#pragma unroll
+        for (int v2 = 1; v2 < 4; ++v2) {
+            const float4 t = wsuml[v2][lk][kx];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         const int ch = cb * DW_CB + qq * 4;
-        if (ch < c && (k < K || kx == P)) {
+        if (ch < c) {
             const int slot = k < K ? k * K + kx : K * K;
             float* dst = partials + ((int64_t)sp * c + ch) * NS + slot;
             dst[0] = s.x; dst[NS] = s.y; dst[2 * NS] = s.z; dst[3 * NS] = s.w;
@@ -246,13 +373,16 @@ extern "C" int tr_dwconv(void* stream, tr_view in, tr_view out, const float* wei
     TR_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, TR_EINVAL, "tr_dwconv: bad dims n=%d h=%d w=%d c=%d (c must be a multiple of 4)", n, h, w, c);
     TR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, TR_EUNSUPPORTED, "tr_dwconv: kernel size %d is not built (3, 5, 7)", ksize);
     TR_REQUIRE(view_has(in, c) && view_has(out, c) && weight, TR_EINVAL, "tr_dwconv: in / out views must hold c=%d channels and weight must be set", c);
+    TR_REQUIRE(tr::view_vec4_ok(in), TR_EALIGN, "tr_dwconv: the input view must allow aligned 4-channel access (offset / stride multiples of 4)");
+    TR_REQUIRE((int64_t)h * w * in.cstride * tr::esize(in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED, "tr_dwconv: one image of the input view must stay below 2 GiB");
     const DwGeom g = dw_geom(n, h, w, c);
     TR_REQUIRE(g.nsp * g.ncb < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_dwconv: grid too large");
     const dim3 grid((unsigned)(g.nsp * g.ncb));
     hipStream_t st = (hipStream_t)stream;
     const int vin = tr::view_vec4_ok(in), vout = tr::view_vec4_ok(out);
-#define TR_DW(K) hipLaunchKernelGGL(dwconv_kernel<K>, grid, dim3(256), 0, st, in, out, weight, bias, h, w, c, flip ? 1 : 0, g.nstrips, g.ncolblk, g.ncb, vin, vout)
-    if (ksize == 7) TR_DW(7); else if (ksize == 5) TR_DW(5); else TR_DW(3);
+#define TR_DW(K, H) hipLaunchKernelGGL((dwconv_kernel<K, H>), grid, dim3(256), 0, st, in, out, weight, bias, h, w, c, flip ? 1 : 0, g.nstrips, g.ncolblk, g.ncb, vin, vout)
+    if (in.dtype == TR_F32) { if (ksize == 7) TR_DW(7, false); else if (ksize == 5) TR_DW(5, false); else TR_DW(3, false); }
+    else { if (ksize == 7) TR_DW(7, true); else if (ksize == 5) TR_DW(5, true); else TR_DW(3, true); }
 #undef TR_DW
     return tr::launch_status("tr_dwconv");
 }
@@ -267,15 +397,20 @@ extern "C" int tr_dwconv_wgrad(void* stream, tr_view in, tr_view gy, float* dw, 
     TR_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, TR_EINVAL, "tr_dwconv_wgrad: bad dims n=%d h=%d w=%d c=%d", n, h, w, c);
     TR_REQUIRE(ksize == 3 || ksize == 5 || ksize == 7, TR_EUNSUPPORTED, "tr_dwconv_wgrad: kernel size %d is not built (3, 5, 7)", ksize);
     TR_REQUIRE(view_has(in, c) && view_has(gy, c) && dw && partials, TR_EINVAL, "tr_dwconv_wgrad: in / gy views must hold c=%d channels; dw and partials must be set", c);
+    TR_REQUIRE(tr::view_vec4_ok(in) && tr::view_vec4_ok(gy) && in.dtype == gy.dtype, TR_EALIGN,
+               "tr_dwconv_wgrad: in / gy views must share a dtype and allow aligned 4-channel access");
+    TR_REQUIRE((int64_t)h * w * (in.cstride > gy.cstride ? in.cstride : gy.cstride) * tr::esize(in.dtype) < (int64_t)0x7fffff00, TR_EUNSUPPORTED,
+               "tr_dwconv_wgrad: one image of a view must stay below 2 GiB");
     const size_t need = tr_dwconv_wgrad_workspace_bytes(n, h, w, c, ksize);
     TR_REQUIRE(partials_bytes >= need, TR_EINVAL, "tr_dwconv_wgrad: workspace too small (need %zu bytes)", need);
     const DwGeom g = dw_geom(n, h, w, c);
-    TR_REQUIRE(g.nsp * g.ncb * ksize < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_dwconv_wgrad: grid too large");
-    const dim3 grid((unsigned)(g.nsp * g.ncb * ksize));
+    TR_REQUIRE(g.nsp * g.ncb < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_dwconv_wgrad: grid too large");
+    const dim3 grid((unsigned)(g.nsp * g.ncb));
     hipStream_t st = (hipStream_t)stream;
     const int vin = tr::view_vec4_ok(in), vgy = tr::view_vec4_ok(gy);
-#define TR_DWG(K) hipLaunchKernelGGL(dwconv_wgrad_kernel<K>, grid, dim3(256), 0, st, in, gy, partials, h, w, c, g.nstrips, g.ncolblk, g.ncb, vin, vgy)
-    if (ksize == 7) TR_DWG(7); else if (ksize == 5) TR_DWG(5); else TR_DWG(3);
+#define TR_DWG(K, H) hipLaunchKernelGGL((dwconv_wgrad_kernel<K, H>), grid, dim3(256), 0, st, in, gy, partials, h, w, c, g.nstrips, g.ncolblk, g.ncb, vin, vgy)
+    if (in.dtype == TR_F32) { if (ksize == 7) TR_DWG(7, false); else if (ksize == 5) TR_DWG(5, false); else TR_DWG(3, false); }
+    else { if (ksize == 7) TR_DWG(7, true); else if (ksize == 5) TR_DWG(5, true); else TR_DWG(3, true); }
 #undef TR_DWG
     const int ns = ksize * ksize + 1;
     hipLaunchKernelGGL(dwconv_wgrad_finish_kernel, dim3((unsigned)((c * ns + 3) / 4)), dim3(256), 0, st, partials, g.nsp, c, ns, dw, db, accumulate ? 1 : 0);
