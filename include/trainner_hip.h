@@ -371,6 +371,24 @@ int tr_tile_normalize(void* stream, const float* acc, const float* wmap, int c, 
 int tr_filter2d(void* stream, const float* img_nchw, const float* kernels, int per_sample, int n, int c, int h, int w, int k, float* out_nchw);
 int tr_quantize_u8(void* stream, const float* x, float* y, int64_t n);
 
+/* ---- OTF degradation stages of RealESRGANModel.feed_data (models/realesrgan_model.py:456-664), fp32 NCHW planes ------------------------
+ * tr_resample_axis: one 1-D pass of a separable resize: out[o] = sum_t weights[o][t] * in[idx[o][t]] along x (axis 1) or y (axis 0); idx / weights are
+ *              device tables of out_len x taps entries built by the host for data/degradations.py:961-1021 `resize_pt` (F.interpolate bilinear /
+ *              bicubic with antialias, nearest-exact, nearest; Lanczos-3 prefilter with reflect padding + bicubic) ; clamp01 != 0 applies the
+ *              trailing .clamp(0, 1).
+ * tr_crop_nchw: img[:, :, top:top+out_h, left:left+out_w] (paired_random_crop, data/transforms.py:118-137).
+ * tr_gain_noise_clamp: clamp(x * gain[channel] + noise * noise_std, 0, 1): exposure / colour temperature / sensor noise
+ *              (models/paragon_otf_degradations.py:345-414); gain_host = c floats on the host, noise optional (device, same shape).
+ * tr_filter2d_zeropad: F.conv2d(img, one k x k kernel repeated per channel, padding = pad, groups = c): motion blur (:251-272) and the box blur of
+ *              the oversharpening stage (realesrgan_model.py:215-232); output is (h + 2 pad - k + 1) x (w + 2 pad - k + 1).
+ * tr_axpby_clamp01: clamp(a * wa + b * wb, 0, 1)  (img + (img - blurred) * strength, realesrgan_model.py:234-241). */
+int tr_resample_axis(void* stream, const float* src, float* dst, int64_t planes, int in_h, int in_w, int axis, int out_len, const int* idx,
+                     const float* weights, int taps, int clamp01);
+int tr_crop_nchw(void* stream, const float* src, float* dst, int64_t planes, int in_h, int in_w, int top, int left, int out_h, int out_w);
+int tr_gain_noise_clamp(void* stream, const float* src, const float* noise, float* dst, int n, int c, int64_t hw, const float* gain_host, float noise_std);
+int tr_filter2d_zeropad(void* stream, const float* img_nchw, const float* kernel, int64_t planes, int h, int w, int k, int pad, float* out);
+int tr_axpby_clamp01(void* stream, const float* a, float wa, const float* b, float wb, float* out, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

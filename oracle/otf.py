@@ -1,0 +1,122 @@
+"""OTF degradation stages -- CPU restatement (test infrastructure only, see oracle/__init__.py).
+
+Follows, function by function,
+  resize_pt / _resample / _lanczos / _ramp / _sinc     /root/reference/traiNNer/data/degradations.py:961-1021
+  filter2d                                             /root/reference/traiNNer/utils/img_process_util.py:8-32   (pinned: tests/golden/filter2d.pt)
+  motion blur / exposure / colour temperature / sensor noise        /root/reference/traiNNer/models/paragon_otf_degradations.py:251-294,345-414
+  oversharpening, aliasing                             /root/reference/traiNNer/models/realesrgan_model.py:193-241,365-402
+  the stage order and RNG draws of feed_data           /root/reference/traiNNer/models/realesrgan_model.py:456-664
+The reference modules themselves do not import here (cv2 / torchvision / msgspec are absent), and RealESRGANModel has no CPU path at all
+(hard-coded .cuda()): resizes are pinned on torch's own F.interpolate, which is what the reference calls; the
+stochastic pipeline as a whole is "parity unpinned" beyond that.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch.nn import functional as F
+
+ANTIALIAS_MODES = {"bicubic", "bilinear"}
+
+
+def _sinc(x):
+    return torch.where(x != 0, torch.sin(math.pi * x) / (math.pi * x), x.new_ones([]))
+
+
+def _lanczos(x, a):
+    cond = torch.logical_and(-a < x, x < a)
+    out = torch.where(cond, _sinc(x) * _sinc(x / a), x.new_zeros([]))
+    return out / out.sum()
+
+
+def _ramp(ratio, width):
+    n = math.ceil(width / ratio + 1)
+    out = torch.empty([n])
+    cur = 0
+    for i in range(out.shape[0]):
+        out[i] = cur
+        cur += ratio
+    return torch.cat([-out[1:].flip([0]), out])[1:-1]
+
+
+def _resample(inp, size, a=3):
+    n, c, h, w = inp.shape
+    dh, dw = size
+    inp = inp.reshape([n * c, 1, h, w])
+    if dh < h:
+        kh = _lanczos(_ramp(dh / h, a), a).to(inp.device, inp.dtype)
+        ph = (kh.shape[0] - 1) // 2
+        inp = F.conv2d(F.pad(inp, (0, 0, ph, ph), "reflect"), kh[None, None, :, None], padding=0)
+    if dw < w:
+        kw = _lanczos(_ramp(dw / w, a), a).to(inp.device, inp.dtype)
+        pw = (kw.shape[0] - 1) // 2
+        inp = F.conv2d(F.pad(inp, (pw, pw, 0, 0), "reflect"), kw[None, None, None, :], padding=0)
+    inp = inp.view([n, c, h, w])
+    return F.interpolate(inp, size, mode="bicubic", align_corners=False).clamp(0, 1)
+
+
+def resize_pt(img, mode, scale_factor=0, size=(0, 0)):
+    if scale_factor == 0 and tuple(size) == (0, 0):
+        raise ValueError("scale_factor or size is required")
+    if scale_factor != 0:
+        size = (round(img.shape[2] * scale_factor), round(img.shape[3] * scale_factor))
+    if mode == "lanczos":
+        return _resample(img, size)
+    return F.interpolate(img, size=size, mode=mode, antialias=mode in ANTIALIAS_MODES).clamp(0, 1)
+
+
+def filter2d(img, kernel):
+    k = kernel.size(-1)
+    b, c, h, w = img.size()
+    if k % 2 == 1:
+        img = F.pad(img, (k // 2, k // 2, k // 2, k // 2), mode="reflect")
+    else:
+        raise ValueError("Wrong kernel size")
+    ph, pw = img.size()[-2:]
+    if kernel.size(0) == 1:
+        img = img.view(b * c, 1, ph, pw)
+        kernel = kernel.view(1, 1, k, k)
+        return F.conv2d(img, kernel, padding=0).view(b, c, h, w)
+    img = img.view(1, b * c, ph, pw)
+    kernel = kernel.view(b, 1, k, k).repeat(1, c, 1, 1).view(b * c, 1, k, k)
+    return F.conv2d(img, kernel, groups=b * c).view(b, c, h, w)
+
+
+def motion_blur(img, kernel, ks):
+    return F.conv2d(img, kernel.reshape(1, 1, ks, ks).repeat(img.size(1), 1, 1, 1), padding=ks // 2, groups=img.size(1))
+
+
+def exposure(img, factor):
+    return torch.clamp(img * factor, 0, 1)
+
+
+def color_temperature(img, shift):
+    r, g, b = img[:, 0:1], img[:, 1:2], img[:, 2:3]
+    if shift > 0:
+        r = r * (1 + shift * 0.3)
+        g = g * (1 + shift * 0.1)
+    else:
+        b = b * (1 - shift * 0.3)
+        g = g * (1 - shift * 0.1)
+    return torch.clamp(torch.cat([r, g, b], dim=1), 0, 1)
+
+
+def sensor_noise(img, noise, std):
+    return torch.clamp(img + noise * std, 0, 1)
+
+
+def oversharpen(img, strength):
+    wt = torch.ones(1, 1, 5, 5) / 25
+    blurred = F.conv2d(img, wt.repeat(img.size(1), 1, 1, 1), padding=2, groups=img.size(1))
+    return torch.clamp(img + (img - blurred) * strength, 0, 1)
+
+
+def aliasing(img, scale_factor):
+    h, w = img.shape[2:]
+    down = F.interpolate(img, size=(int(h * scale_factor), int(w * scale_factor)), mode="nearest")
+    return F.interpolate(down, size=(h, w), mode="nearest")
+
+
+def clamp_round(x):
+    return torch.clamp((x * 255.0).round(), 0, 255) / 255.0

@@ -42,3 +42,151 @@ def test_clamp_round_and_pair_pool(cuda):
     assert torch.equal(a[:, 0, 0, 0], b[:, 0, 0, 0])                    # lq / gt stay paired through the shuffle
     vals = sorted(pool.queue_lr[:, 0, 0, 0].tolist())
     assert vals.count(9.0) == 2 and len(vals) == 6
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "bicubic", "nearest-exact", "lanczos"])
+@pytest.mark.parametrize("shape,size", [((4, 3, 256, 256), (64, 64)), ((2, 3, 37, 53), (23, 31)), ((1, 1, 20, 24), (33, 40)), ((1, 3, 40, 40), (40, 17))])
+def test_resize_pt_matches_torch_interpolate(cuda, mode, shape, size):
+    """`resize_pt` (data/degradations.py:996-1021) = F.interpolate (+ antialias) / Lanczos prefilter + bicubic: the HIP gathers vs the same
+    calls on the CPU; 3e-6 absolute on [0, 1] images (fp32 summation order)."""
+    from oracle import otf as OO
+    from trainner_redux_amd.data import otf
+
+    img = torch.rand(*shape, generator=torch.Generator().manual_seed(3))
+    ref = OO.resize_pt(img, mode, size=size)
+    out = otf.resize_pt(img.to(cuda), mode, size=size)
+    assert out.shape == ref.shape
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < (1e-7 if mode == "nearest-exact" else 3e-6), err
+    ref2 = OO.resize_pt(img, mode, scale_factor=0.5)
+    assert (otf.resize_pt(img.to(cuda), mode, scale_factor=0.5).cpu() - ref2).abs().max().item() < 3e-6
+
+
+def test_elementwise_and_blur_stages_match_oracle(cuda):
+    from oracle import otf as OO
+    from trainner_redux_amd.data import otf
+
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(2, 3, 45, 52, generator=g)
+    d = img.to(cuda)
+    assert torch.allclose(otf.gain_noise_clamp(d, 1.7).cpu(), OO.exposure(img, 1.7), atol=1e-7)
+    for shift in (0.15, -0.12):
+        gains = (1 + shift * 0.3, 1 + shift * 0.1, 1.0) if shift > 0 else (1.0, 1 - shift * 0.1, 1 - shift * 0.3)
+        assert torch.allclose(otf.gain_noise_clamp(d, gains).cpu(), OO.color_temperature(img, shift), atol=1e-7)
+    noise = torch.randn(img.shape, generator=g)
+    assert torch.allclose(otf.gain_noise_clamp(d, 1.0, noise.to(cuda), 0.07).cpu(), OO.sensor_noise(img, noise, 0.07), atol=1e-7)
+    for ks, angle in ((7, 30.0), (6, 120.0), (15, 271.0)):            # even sizes grow the image by one, as F.conv2d(padding=k // 2) does
+        k = otf.motion_blur_kernel(ks, angle)
+        ref = OO.motion_blur(img, k, ks)
+        out = otf.conv_shared_zeropad(d, k, ks // 2)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 2e-6
+    s = 1.4
+    blurred = otf.conv_shared_zeropad(d, torch.full((5, 5), 1.0 / 25.0), 2)
+    assert (otf.axpby_clamp01(d, 1.0 + s, blurred, -s).cpu() - OO.oversharpen(img, s)).abs().max().item() < 2e-6
+    f = 0.73
+    h, w = img.shape[2:]
+    al = otf.resize_pt(otf.resize_pt(d, "nearest", size=(int(h * f), int(w * f)), clamp=False), "nearest", size=(h, w), clamp=False)
+    assert torch.equal(al.cpu(), OO.aliasing(img, f))
+    c = otf.crop(d, 5, 7, 20, 30)
+    assert torch.equal(c.cpu(), img[:, :, 5:25, 7:37])
+
+
+def _otf_opt(**kw):
+    from trainner_redux_amd.utils.options import parse_options_dict
+
+    base = dict(name="t", scale=4, num_gpu=1, path={}, manual_seed=11, high_order_degradation=True, queue_size=4,
+                network_g=dict(type="span", feature_channels=16, norm=True),
+                datasets=dict(train=dict(name="x", type="realesrgandataset", lq_size=16, batch_size_per_gpu=2)),
+                train=dict(total_iter=100, ema_decay=0.999, optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
+                           losses=[dict(type="l1loss", loss_weight=1.0)]))
+    base.update(kw)
+    return parse_options_dict(base)
+
+
+def test_degrader_follows_the_reference_stage_order_and_rng(cuda):
+    """Whole stage list with every built stage switched on, against the oracle stages driven by a twin RNG in the reference's draw order
+    (realesrgan_model.py:456-664).  Compression format `heif`: PIL has no HEIF plugin here, so -- exactly like the reference -- samples pass
+    through and the comparison stays exact; the codec round-trip is covered separately."""
+    import random
+
+    import numpy as np
+
+    from oracle import otf as OO
+    from trainner_redux_amd.data import otf
+
+    kw = dict(motion_blur_prob=1.0, motion_blur_kernel_size=(7, 7), blur_prob=1.0, sensor_noise_prob=1.0, exposure_prob=1.0, color_temp_prob=1.0,
+              oversharpen_prob=1.0, aliasing_prob=1.0, resize_mode_list3=["bicubic"], resize_mode_prob3=[1.0], compression_formats=["heif"],
+              compression_weights=[1.0], editing_prob=1.0, editing_exposure_prob=1.0)
+    opt = _otf_opt(**kw)
+    deg = otf.OTFDegrader(opt, rng=np.random.default_rng(5), rnd=random.Random(6))
+    g = torch.Generator().manual_seed(2)
+    gt = torch.rand(2, 3, 96, 96, generator=g)
+    k1 = torch.rand(2, 21, 21, generator=g); k1 = k1 / k1.sum((1, 2), keepdim=True)
+    sinc = torch.zeros(2, 21, 21); sinc[:, 10, 10] = 1.0
+    torch.manual_seed(77)
+    out = deg.degrade(gt.to(cuda), k1.to(cuda), sinc.to(cuda))
+    # ---- the same walk on the CPU
+    rng, rnd = np.random.default_rng(5), random.Random(6)
+    torch.manual_seed(77)
+    x = gt
+    rng.uniform(); rng.uniform()                                          # lens, chromatic gates
+    assert rng.uniform() < 1.0
+    ks = rnd.randint(7, 7); angle = rng.uniform(0, 360)
+    x = OO.motion_blur(x, otf.motion_blur_kernel(ks, angle), ks)
+    rng.uniform(); x = OO.filter2d(x, k1)
+    rng.uniform()                                                         # demosaic gate
+    rng.uniform(); std = rng.uniform(0.01, 0.1)
+    noise = torch.randn(x.shape, device=cuda).cpu()                       # the device generator drew the field: replay it from the same seed
+    x = OO.sensor_noise(x, noise, std)
+    rng.uniform()                                                         # rolling shutter gate
+    rng.uniform(); x = OO.exposure(x, rng.uniform(0.5, 2.0))
+    rng.uniform(); x = OO.color_temperature(x, rng.uniform(-0.2, 0.2))
+    rng.uniform(); x = OO.oversharpen(x, rng.uniform(1.0, 2.0))
+    rng.uniform(); x = OO.aliasing(x, rng.uniform(0.6, 0.9))
+    mode = rnd.choices(["bicubic"], weights=[1.0])[0]
+    x = OO.resize_pt(x, mode, size=(24, 24))
+    x = OO.filter2d(x, sinc)
+    rng.choice(["heif"], p=[1.0]); rng.uniform(70, 90)                    # format + quality draws; no plugin -> unchanged
+    rng.uniform()                                                         # recompression gate
+    rng.uniform(); rng.uniform(); x = OO.exposure(x, rng.uniform(0.9, 1.1)); rng.uniform()
+    assert out.shape == x.shape
+    err = (out.cpu() - x).abs().max().item()
+    assert err < 2e-5, err
+    assert deg.rng.uniform() == rng.uniform()                             # both streams consumed the same number of draws
+
+
+def test_jpeg_round_trip_is_the_host_codec(cuda):
+    from trainner_redux_amd.data import otf
+
+    img = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(4)).mul(0.5).add(0.25)
+    out = otf.compress_round_trip(img.to(cuda), "jpeg", 60.7)
+    again = otf.compress_round_trip(img, "jpeg", 60.7)                    # the codec runs on the host either way: same bytes
+    assert out.is_cuda and torch.equal(out.cpu(), again) and not torch.equal(again, img)
+    assert (again - img).abs().mean() < 0.2 and torch.equal(again, (again * 255).round() / 255)      # 8-bit levels
+    assert torch.equal(otf.compress_round_trip(img, "nosuchformat", 50), img)
+
+
+def test_realesrgan_model_trains_on_otf_pairs(cuda):
+    """build_model picks RealESRGANModel for `high_order_degradation`; feed_data turns GT + kernels into a (lq, gt) pair of the configured
+    tile size on 8-bit levels, the pair pool fills then shuffles, and optimize_parameters runs on the result."""
+    from trainner_redux_amd.models import RealESRGANModel, build_model
+
+    model = build_model(_otf_opt(compression_formats=["jpeg"], compression_weights=[1.0], blur_prob=1.0))
+    assert isinstance(model, RealESRGANModel)
+    g = torch.Generator().manual_seed(8)
+    for it in range(1, 4):
+        gt = torch.rand(2, 3, 128, 128, generator=g)
+        k = torch.rand(2, 21, 21, generator=g); k = k / k.sum((1, 2), keepdim=True)
+        sinc = torch.zeros(2, 21, 21); sinc[:, 10, 10] = 1.0
+        model.feed_data({"gt": gt, "kernel1": k, "kernel2": k, "sinc_kernel": sinc})
+        assert model.lq.shape == (2, 3, 16, 16) and model.gt.shape == (2, 3, 64, 64)
+        lq_host = model.lq.cpu()
+        assert torch.equal(lq_host, (lq_host * 255).round() / 255)          # 8-bit levels (checked with the CPU's correctly rounded division)
+        model.optimize_parameters(it, 0, True)
+    log = model.get_current_log()
+    assert log["l_g_l1"] > 0 and model.otf.pool.queue_ptr == 4
+    with pytest.raises(NotImplementedError):
+        build_model(_otf_opt(lens_distort_prob=0.5))
+    model.is_train = False
+    model.feed_data({"lq": torch.rand(1, 3, 8, 8), "gt": torch.rand(1, 3, 32, 32)})      # validation batches stay paired
+    assert model.lq.shape == (1, 3, 8, 8)

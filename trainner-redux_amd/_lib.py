@@ -132,6 +132,11 @@ SYMBOLS = {
     "tr_tile_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "tr_filter2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "tr_quantize_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "tr_resample_axis": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "tr_crop_nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_gain_noise_clamp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_float), C.c_float]),
+    "tr_filter2d_zeropad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "tr_axpby_clamp01": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int64]),
     "tr_span_gate": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64]),
     "tr_span_gate_bwd": (C.c_int, [C.c_void_p, View, View, View, View, View, C.c_int, C.c_int64]),
     "tr_dwconv": (C.c_int, [C.c_void_p, View, View, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
