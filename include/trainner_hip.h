@@ -388,6 +388,11 @@ int tr_crop_nchw(void* stream, const float* src, float* dst, int64_t planes, int
 int tr_gain_noise_clamp(void* stream, const float* src, const float* noise, float* dst, int n, int c, int64_t hw, const float* gain_host, float noise_std);
 int tr_filter2d_zeropad(void* stream, const float* img_nchw, const float* kernel, int64_t planes, int h, int w, int k, int pad, float* out);
 int tr_axpby_clamp01(void* stream, const float* a, float wa, const float* b, float wb, float* out, int64_t n);
+/* tr_warp_bilinear: F.grid_sample(mode="bilinear", align_corners=False) over a grid computed in the kernel; params_host = 4 floats.
+ *   mode 0 lens distortion (paragon_otf_degradations.py:297-343; params[0] = strength; reflection padding; the reference's swapped grid axes kept),
+ *   mode 1 rolling shutter (:417-456; params[0] = slant = strength * h / w; reflection padding),
+ *   mode 2 chromatic aberration (realesrgan_model.py:244-311; params[ch] = affine scale of channel ch, 1 = untouched; zero padding, clamp to [0, 1]). */
+int tr_warp_bilinear(void* stream, const float* src, float* dst, int n, int c, int h, int w, int mode, const float* params_host);
 
 #ifdef __cplusplus
 }

@@ -120,3 +120,37 @@ def aliasing(img, scale_factor):
 
 def clamp_round(x):
     return torch.clamp((x * 255.0).round(), 0, 255) / 255.0
+
+
+def lens_distortion(img, strength):
+    """paragon_otf_degradations.py:310-343 (the `ij` meshgrid is stacked as (rows, cols), i.e. the grid's x coordinate runs over rows)."""
+    b, _, h, w = img.shape
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+    r = torch.sqrt(gx ** 2 + gy ** 2)
+    rd = r * (1 + strength * r ** 2)
+    rd[r == 0] = 0
+    r[r == 0] = 1e-6
+    grid = torch.stack([gx * (rd / r), gy * (rd / r)], dim=-1).unsqueeze(0).repeat(b, 1, 1, 1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+
+
+def rolling_shutter(img, strength):
+    """paragon_otf_degradations.py:430-456."""
+    b, _, h, w = img.shape
+    slant = strength * h / w
+    gy, gx = torch.meshgrid(torch.linspace(-1, 1, h), torch.linspace(-1, 1, w), indexing="ij")
+    grid = torch.stack([gx + slant * gy, gy], dim=-1).unsqueeze(0).repeat(b, 1, 1, 1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+
+
+def chromatic_aberration(img):
+    """realesrgan_model.py:262-311."""
+    b = img.shape[0]
+    out = []
+    for ch, s in ((0, 1.001), (1, None), (2, 0.999)):
+        x = img[:, ch:ch + 1]
+        if s is not None:
+            theta = torch.tensor([[[s, 0, 0], [0, s, 0]]], dtype=torch.float32).repeat(b, 1, 1)
+            x = F.grid_sample(x, F.affine_grid(theta, x.size(), align_corners=False), align_corners=False, mode="bilinear")
+        out.append(x)
+    return torch.clamp(torch.cat(out, dim=1), 0, 1)

@@ -79,6 +79,64 @@ __global__ __launch_bounds__(256) void axpby_clamp_kernel(const float* __restric
         out[i] = fminf(fmaxf(a[i] * wa + b[i] * wb, 0.f), 1.f);
 }
 
+// ---- F.grid_sample(bilinear, align_corners=False) over analytic grids ---------------------------------------------------------------
+// mode 0  lens distortion   (paragon_otf_degradations.py:312-343): with u = lin(H)[y], v = lin(W)[x] (lin = torch.linspace(-1, 1, n)),
+//         f = 1 + k (u^2 + v^2): the grid's x coordinate is u f and its y coordinate v f -- the reference stacks its `ij` meshgrid in that
+//         order, i.e. it samples the TRANSPOSED position; kept as it is.  Reflection padding.
+// mode 1  rolling shutter   (:430-456): x' = lin(W)[x] + slant * lin(H)[y], y' = lin(H)[y].  Reflection padding.
+// mode 2  per-channel scale (realesrgan_model.py:262-311, affine_grid of diag(s, s)): x' = s (2x + 1 - W) / W, same for y; s = p[channel].
+//         Zero padding, clamp to [0, 1].
+__device__ __forceinline__ float lin11(int i, int n) {          // torch.linspace(-1, 1, n)[i]
+    if (n == 1) return -1.f;
+    const float step = 2.f / (float)(n - 1);
+    return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+__device__ __forceinline__ float reflect_coord(float in, int size) {   // ATen reflect_coordinates(in, -1, 2 size - 1) then clip
+    const float mn = -0.5f, span = (float)size;
+    in = fabsf(in - mn);
+    const float extra = fmodf(in, span);
+    const int flips = (int)floorf(in / span);
+    const float r = (flips & 1) == 0 ? extra + mn : span - extra + mn;
+    return fminf((float)(size - 1), fmaxf(r, 0.f));
+}
+__global__ __launch_bounds__(256) void warp_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c, int h, int w, int mode, float p0,
+                                                             float p1, float p2, float p3) {
+    const int64_t total = (int64_t)n * c * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const int64_t r = i / w;
+        const int y = (int)(r % h);
+        const int64_t pl = r / h;
+        const int ch = (int)(pl % c);
+        float gx, gy;
+        if (mode == 0) {
+            const float u = lin11(y, h), v = lin11(x, w);
+            float rr = sqrtf(u * u + v * v);
+            float rd = rr * (1.f + p0 * rr * rr);
+            if (rr == 0.f) { rd = 0.f; rr = 1e-6f; }
+            const float f = rd / rr;
+            gx = u * f; gy = v * f;
+        } else if (mode == 1) {
+            gy = lin11(y, h);
+            gx = lin11(x, w) + p0 * gy;
+        } else {
+            const float s = ch == 0 ? p0 : ch == 1 ? p1 : ch == 2 ? p2 : p3;
+            gx = s * ((2.f * x + 1.f) / (float)w - 1.f);
+            gy = s * ((2.f * y + 1.f) / (float)h - 1.f);
+        }
+        float ix = ((gx + 1.f) * (float)w - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+        if (mode != 2) { ix = reflect_coord(ix, w); iy = reflect_coord(iy, h); }
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float tx = ix - fx, ty = iy - fy;
+        const float* sp = src + pl * h * w;
+        auto at = [&](int yy, int xx) { return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? sp[(int64_t)yy * w + xx] : 0.f; };
+        float v = at(y0, x0) * (1.f - tx) * (1.f - ty) + at(y0, x0 + 1) * tx * (1.f - ty) + at(y0 + 1, x0) * (1.f - tx) * ty + at(y0 + 1, x0 + 1) * tx * ty;
+        if (mode == 2) v = fminf(fmaxf(v, 0.f), 1.f);
+        dst[i] = v;
+    }
+}
+
 struct Gain4 { float g[4]; };
 __global__ __launch_bounds__(256) void gain_noise_kernel(const float* __restrict__ src, const float* __restrict__ noise, float* __restrict__ dst, int c, int64_t hw,
                                                           int64_t total, Gain4 gain, float noise_std) {
@@ -140,4 +198,12 @@ extern "C" int tr_axpby_clamp01(void* stream, const float* a, float wa, const fl
     TR_REQUIRE(a && b && out && n > 0, TR_EINVAL, "tr_axpby_clamp01: bad arguments");
     hipLaunchKernelGGL(axpby_clamp_kernel, dim3(sweep_grid(n)), dim3(256), 0, (hipStream_t)stream, a, wa, b, wb, out, n);
     return tr::launch_status("tr_axpby_clamp01");
+}
+
+extern "C" int tr_warp_bilinear(void* stream, const float* src, float* dst, int n, int c, int h, int w, int mode, const float* params_host) {
+    TR_REQUIRE(src && dst && params_host && n > 0 && c > 0 && h > 0 && w > 0, TR_EINVAL, "tr_warp_bilinear: bad arguments");
+    TR_REQUIRE(mode >= 0 && mode <= 2 && (mode != 2 || c <= 4), TR_EINVAL, "tr_warp_bilinear: mode %d (0 lens, 1 shear, 2 per-channel scale with <= 4 channels)", mode);
+    hipLaunchKernelGGL(warp_bilinear_kernel, dim3(sweep_grid((int64_t)n * c * h * w)), dim3(256), 0, (hipStream_t)stream, src, dst, n, c, h, w, mode, params_host[0],
+                       params_host[1], params_host[2], params_host[3]);
+    return tr::launch_status("tr_warp_bilinear");
 }

@@ -287,6 +287,18 @@ def axpby_clamp01(a: torch.Tensor, wa: float, b: torch.Tensor, wb: float) -> tor
     return out
 
 
+def warp_bilinear(img: torch.Tensor, mode: int, params) -> torch.Tensor:
+    """grid_sample(bilinear, align_corners=False) over the analytic grids of the lens (0) / rolling-shutter (1) / chromatic (2) stages."""
+    import ctypes as C
+
+    img = img.contiguous().float()
+    b, c, h, w = img.shape
+    p = [float(v) for v in params] + [1.0] * (4 - len(params))
+    out = torch.empty_like(img)
+    L.check(L.lib().tr_warp_bilinear(stream_ptr(), img.data_ptr(), out.data_ptr(), b, c, h, w, mode, (C.c_float * 4)(*p)), "tr_warp_bilinear")
+    return out
+
+
 def motion_blur_kernel(kernel_size: int, angle: float) -> torch.Tensor:
     """models/paragon_otf_degradations.py:276-294."""
     center = kernel_size // 2
@@ -327,7 +339,7 @@ def compress_round_trip(img: torch.Tensor, format_name: str, quality: float) -> 
 
 
 _OTF_DEFAULTS = dict(   # utils/redux_options.py:503-901
-    p_clean=0, lens_distort_prob=0, chromatic_aberration_prob=0, motion_blur_prob=0, motion_blur_kernel_size=(5, 15), motion_blur_angle_range=(0, 360),
+    p_clean=0, lens_distort_prob=0, lens_distort_strength_range=(-0.3, 0.3), rolling_shutter_strength_range=(-0.1, 0.1), chromatic_aberration_prob=0, motion_blur_prob=0, motion_blur_kernel_size=(5, 15), motion_blur_angle_range=(0, 360),
     blur_prob=0, demosaic_prob=0, sensor_noise_prob=0, sensor_noise_std_range=(0.01, 0.1), rolling_shutter_prob=0, exposure_prob=0,
     exposure_factor_range=(0.5, 2.0), color_temp_prob=0, color_temp_shift_range=(-0.2, 0.2), oversharpen_prob=0, oversharpen_strength=(1.0, 2.0),
     aliasing_prob=0, aliasing_scale_range=(0.6, 0.9), resize_mode_list3=["bilinear", "bicubic", "nearest-exact", "lanczos"],
@@ -336,14 +348,14 @@ _OTF_DEFAULTS = dict(   # utils/redux_options.py:503-901
     recompression_prob=0, recompression_formats=["jpeg", "webp", "avif", "heif"], recompression_weights=[0.50, 0.35, 0.10, 0.05], editing_prob=0,
     editing_exposure_prob=0, editing_exposure_range=(0.9, 1.1), editing_oversharpen_prob=0, editing_oversharpen_strength=(1.0, 1.3), queue_size=120,
     enable_sequences=False)
-_UNBUILT = ("lens_distort_prob", "chromatic_aberration_prob", "demosaic_prob", "rolling_shutter_prob")
+_UNBUILT = ("demosaic_prob",)                      # an OpenCV (cv2) round trip per sample in the reference; cv2 is absent here
 
 
 class OTFDegrader:
     """The training branch of RealESRGANModel.feed_data (models/realesrgan_model.py:456-664), stage for stage and RNG draw for RNG draw
     (numpy Generator = the reference's `RNG.get_rng()`, python `random` for the resize mode / crop / motion-kernel size, torch for the noise
-    field and the pool shuffle), so that a seeded run takes the same decisions.  Stages that are not built (lens distortion, chromatic
-    aberration, demosaicing, rolling shutter: grid_sample / OpenCV bodies) raise at construction when their probability is non-zero."""
+    field and the pool shuffle), so that a seeded run takes the same decisions.  Stages that are not built (
+    demosaicing artifacts: an OpenCV body) raise at construction when their probability is non-zero."""
 
     def __init__(self, opt, rng: np.random.Generator | None = None, rnd=random) -> None:
         self.o = {k: (getattr(opt, k, None) if getattr(opt, k, None) is not None else v) for k, v in _OTF_DEFAULTS.items()}
@@ -371,8 +383,10 @@ class OTFDegrader:
         o, rng = self.o, self.rng
         ori_h, ori_w = gt.shape[2:4]
         out = gt
-        self._gate("lens_distort_prob")                  # one draw per gate, taken or not, like the reference
-        self._gate("chromatic_aberration_prob")
+        if self._gate("lens_distort_prob"):              # one draw per gate, taken or not, like the reference
+            out = warp_bilinear(out, 0, [rng.uniform(o["lens_distort_strength_range"][0], o["lens_distort_strength_range"][1])])
+        if self._gate("chromatic_aberration_prob") and out.shape[1] == 3:
+            out = warp_bilinear(out, 2, [1.001, 1.0, 0.999])
         if self._gate("motion_blur_prob"):
             ks = self.rnd.randint(o["motion_blur_kernel_size"][0], o["motion_blur_kernel_size"][1])
             angle = rng.uniform(o["motion_blur_angle_range"][0], o["motion_blur_angle_range"][1])
@@ -383,7 +397,9 @@ class OTFDegrader:
         if self._gate("sensor_noise_prob"):
             std = rng.uniform(o["sensor_noise_std_range"][0], o["sensor_noise_std_range"][1])
             out = gain_noise_clamp(out, 1.0, torch.randn_like(out), std)
-        self._gate("rolling_shutter_prob")
+        if self._gate("rolling_shutter_prob"):
+            st = rng.uniform(o["rolling_shutter_strength_range"][0], o["rolling_shutter_strength_range"][1])
+            out = warp_bilinear(out, 1, [st * out.shape[2] / out.shape[3]])
         if self._gate("exposure_prob"):
             out = gain_noise_clamp(out, rng.uniform(o["exposure_factor_range"][0], o["exposure_factor_range"][1]))
         if self._gate("color_temp_prob") and out.shape[1] == 3:
