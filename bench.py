@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--losses", default="l1+perceptual", choices=["l1", "l1+perceptual", "l1+perceptualfp16"])
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f16", "f32"], help="f16 = the reference's default AMP mode: fp16 operands + loss scaling")
     ap.add_argument("--gan", action="store_true", help="BASELINE.json configs[2] heads: add the UNetDiscriminatorSN + vanilla GAN term (weight 0.1) and its D update")
+    ap.add_argument("--otf", action="store_true", help="BASELINE.json configs[2] feed: RealESRGANModel -- every step's feed_data runs the on-the-fly degradation "
+                                                       "stages (template values of options/_templates/train/ESRGAN/ESRGAN_OTF_gan.yml) on GT tiles + blur kernels")
     ap.add_argument("--fast-matmul", action="store_true", help="the reference's fast_matmul option: split-bf16 (3 bf16 MFMAs per product) for the fp32-forced VGG; NOT the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational fast_matmul measurement")
@@ -73,6 +75,9 @@ def make_opt(args):
         losses.append(dict(type="ganloss", gan_type="vanilla", loss_weight=0.1))
         extra["network_d"] = dict(type="unetdiscriminatorsn")
         train_extra["optim_d"] = dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99])
+    if args.otf:
+        extra.update(high_order_degradation=True, queue_size=120, blur_prob=0.0, resize_mode_list3=["bilinear", "bicubic", "nearest-exact", "lanczos"],
+                     resize_mode_prob3=[0.25, 0.25, 0.25, 0.25])
     return parse_options_dict(dict(
         **extra,
         name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, fast_matmul=args.fast_matmul, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
@@ -224,6 +229,24 @@ def main():
     gt = torch.rand(n, 3, sc * s, sc * s, device=dev)
     lq = torch.nn.functional.interpolate(gt, scale_factor=1.0 / sc, mode="bicubic", antialias=True).clamp(0, 1)
     batch = {"lq": lq, "gt": gt}
+    if args.otf:
+        # what RealESRGANDataset hands over (data/realesrgan_dataset.py): GT tiles of gt_size + 32 and three 21 x 21 kernels per sample, on the host
+        import numpy as np
+
+        from trainner_redux_amd.data.kernels import random_mixed_kernels
+
+        rng = np.random.default_rng(1024 + rank)
+        kinds, kp = ["iso", "aniso", "generalized_iso", "generalized_aniso", "plateau_iso", "plateau_aniso"], [0.45, 0.25, 0.12, 0.03, 0.12, 0.03]
+
+        def kern(sig):
+            ks = 2 * int(rng.integers(2, 9)) + 1
+            k = random_mixed_kernels(kinds, kp, ks, sig, sig, (-3.14159, 3.14159), (0.5, 4), (1, 2), rng=rng)
+            p = (21 - ks) // 2
+            return torch.from_numpy(np.pad(k, ((p, p), (p, p)))).float()
+
+        pulse = torch.zeros(21, 21); pulse[10, 10] = 1
+        batch = {"gt": torch.rand(n, 3, sc * s + 32, sc * s + 32), "kernel1": torch.stack([kern((0.2, 2)) for _ in range(n)]),
+                 "kernel2": torch.stack([kern((0.2, 1)) for _ in range(n)]), "sinc_kernel": pulse.repeat(n, 1, 1)}
     timer = ConvTimer()
     if not args.no_roofline:
         timer.install()
@@ -268,7 +291,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
             "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
-                                   + f" {args.losses} {args.compute}" + (" +GAN(UNetDiscriminatorSN)" if args.gan else "") + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+                                   + f" {args.losses} {args.compute}" + (" +GAN(UNetDiscriminatorSN)" if args.gan else "") + (" +OTF feed (RealESRGANModel.feed_data per step, host codec round trip included)" if args.otf else "") + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }

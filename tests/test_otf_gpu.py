@@ -194,8 +194,32 @@ def test_realesrgan_model_trains_on_otf_pairs(cuda):
         model.optimize_parameters(it, 0, True)
     log = model.get_current_log()
     assert log["l_g_l1"] > 0 and model.otf.pool.queue_ptr == 4
+    # prefetch: the next batch's feed runs on a side stream; feed_data of the same batch object collects it
+    nxt = {"gt": torch.rand(2, 3, 128, 128, generator=g), "kernel1": k, "kernel2": k, "sinc_kernel": sinc}
+    model.prefetch(nxt)
+    model.optimize_parameters(4, 0, True)
+    model.feed_data(nxt)
+    assert model.lq.shape == (2, 3, 16, 16) and torch.isfinite(model.lq).all() and model._otf_pending is None
+    model.optimize_parameters(5, 0, True)
+    model.prefetch(nxt)
+    with pytest.raises(RuntimeError, match="different batch"):
+        model.feed_data({"gt": nxt["gt"], "kernel1": k, "kernel2": k, "sinc_kernel": sinc})
     with pytest.raises(NotImplementedError):
         build_model(_otf_opt(demosaic_prob=0.5))
     model.is_train = False
     model.feed_data({"lq": torch.rand(1, 3, 8, 8), "gt": torch.rand(1, 3, 32, 32)})      # validation batches stay paired
     assert model.lq.shape == (1, 3, 8, 8)
+
+
+def test_resize_pt_matches_the_reference_function(cuda):
+    """HIP resize against the outputs of the reference's OWN resize_pt (tests/golden/otf_degradations.pt, made by tests/golden/make_golden_otf.py
+    from data/degradations.py loaded by path): 3e-6 absolute on [0, 1] images, nearest-exact bit-exact."""
+    from trainner_redux_amd.data import otf
+
+    fix = torch.load(os.path.join(os.path.dirname(__file__), "golden", "otf_degradations.pt"), weights_only=True)["resize"]
+    for tag, e in fix.items():
+        for mode, ref in e["out"].items():
+            out = otf.resize_pt(e["img"].to(cuda), mode, **e["kw"]).cpu()
+            assert out.shape == ref.shape, (tag, mode)
+            err = (out - ref).abs().max().item()
+            assert err < (1e-7 if mode == "nearest-exact" else 3e-6), (tag, mode, err)

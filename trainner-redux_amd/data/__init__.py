@@ -2,5 +2,6 @@
 from .data_sampler import EnlargedSampler
 from .paired_image_dataset import PairedImageDataset
 from .prefetch import DevicePrefetcher, build_dataloader
+from .realesrgan_dataset import RealESRGANDataset
 
-__all__ = ["EnlargedSampler", "PairedImageDataset", "DevicePrefetcher", "build_dataloader"]
+__all__ = ["EnlargedSampler", "PairedImageDataset", "RealESRGANDataset", "DevicePrefetcher", "build_dataloader"]

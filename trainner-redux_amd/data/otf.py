@@ -311,14 +311,15 @@ def motion_blur_kernel(kernel_size: int, angle: float) -> torch.Tensor:
     return k / k.sum()
 
 
-def compress_round_trip(img: torch.Tensor, format_name: str, quality: float) -> torch.Tensor:
+def compress_round_trip(img: torch.Tensor, format_name: str, quality: float, host: torch.Tensor | None = None) -> torch.Tensor:
     """`ParagonOTF._compress_with_format` body (models/paragon_otf_degradations.py:119-158): a per-sample PIL encode / decode on the HOST --
     the reference does exactly this (`.cpu()` -> uint8 -> codec -> back), so this stage is codec-bound, not a kernel; a format whose PIL
     plugin is missing (AVIF / HEIF here) passes the sample through unchanged, as in the reference."""
     from PIL import Image
 
     fmt = {"jpeg": "JPEG", "webp": "WEBP", "avif": "AVIF", "heif": "HEIF"}.get(format_name)
-    host = img.detach().float().cpu()
+    if host is None:                     # `host`: the same pixels already copied to (pinned) host memory by an earlier async D2H
+        host = img.detach().float().cpu()
     out = []
     for i in range(host.shape[0]):
         if fmt is None:
@@ -373,6 +374,7 @@ class OTFDegrader:
         if self.gt_size is None and ds is not None and getattr(ds, "lq_size", None) is not None:
             self.gt_size = ds.lq_size * self.scale                   # train.py:103-110 derives the one from the other
         self.pool = PairPool(self.o["queue_size"])
+        self._pinned: dict = {}
 
     def _gate(self, key: str) -> bool:
         return self.rng.uniform() < self.o[key]
@@ -380,6 +382,11 @@ class OTFDegrader:
     @torch.no_grad()
     def degrade(self, gt: torch.Tensor, kernel1: torch.Tensor, sinc_kernel: torch.Tensor) -> torch.Tensor:
         """GT batch -> LQ batch at 1/scale (everything before the clamp/round, crop and pool)."""
+        return self._after_codec_stages(self._before_codec_stages(gt, kernel1, sinc_kernel))
+
+    @torch.no_grad()
+    def _before_codec_stages(self, gt: torch.Tensor, kernel1: torch.Tensor, sinc_kernel: torch.Tensor) -> torch.Tensor:
+        """Optics, sensor and ISP stages up to the final resize + sinc filter (realesrgan_model.py:505-569): device work only."""
         o, rng = self.o, self.rng
         ori_h, ori_w = gt.shape[2:4]
         out = gt
@@ -417,8 +424,13 @@ class OTFDegrader:
         assert len(o["resize_mode_list3"]) == len(o["resize_mode_prob3"]), "resize_mode_list3 and resize_mode_prob3 must be the same length"
         mode = self.rnd.choices(o["resize_mode_list3"], weights=o["resize_mode_prob3"])[0]
         out = resize_pt(out, size=(ori_h // self.scale, ori_w // self.scale), mode=mode)
-        out = filter2d(out, sinc_kernel)
-        out = self._compress(out, o["compression_formats"], o["compression_weights"])
+        return filter2d(out, sinc_kernel)
+
+    @torch.no_grad()
+    def _after_codec_stages(self, out: torch.Tensor, host: torch.Tensor | None = None) -> torch.Tensor:
+        """Compression round(s) and the editing stage (realesrgan_model.py:575-609)."""
+        o, rng = self.o, self.rng
+        out = self._compress(out, o["compression_formats"], o["compression_weights"], host)
         if rng.uniform() < o["recompression_prob"]:
             out = self._compress(out, o["recompression_formats"], o["recompression_weights"])
         if rng.uniform() < o["editing_prob"]:
@@ -427,22 +439,44 @@ class OTFDegrader:
             rng.uniform()                                # editing_oversharpen_prob: the reference draws and then does nothing (:604-609)
         return out
 
-    def _compress(self, img, formats, weights):
+    def _compress(self, img, formats, weights, host=None):
         fmt = str(self.rng.choice(formats, p=weights))
         qr = self.o.get(f"compression_{fmt}_range")
         if qr is None:
             return img
-        return compress_round_trip(img, fmt, self.rng.uniform(qr[0], qr[1]))
+        return compress_round_trip(img, fmt, self.rng.uniform(qr[0], qr[1]), host)
 
-    @torch.no_grad()
     def __call__(self, gt: torch.Tensor, kernel1: torch.Tensor, kernel2: torch.Tensor, sinc_kernel: torch.Tensor):
         """-> (lq, gt) training pair: p_clean pass-through or the stage list, 8-bit rounding, paired crop, pair pool."""
+        return self.finish(self.start(gt, kernel1, kernel2, sinc_kernel))
+
+    @torch.no_grad()
+    def start(self, gt: torch.Tensor, kernel1: torch.Tensor, kernel2: torch.Tensor, sinc_kernel: torch.Tensor) -> dict:
+        """First half of the feed: everything up to the host codec, plus an asynchronous copy of the pre-codec batch into pinned memory.
+        `finish` does the rest.  Splitting here lets a caller enqueue a training step between the two halves, so that the codec's
+        device -> host hop waits on an event that completed long ago instead of draining the launch queue (RNG draw order is unchanged:
+        start(1) finish(1) start(2) finish(2) ... is the order of the unsplit calls)."""
         if self.gt_size is None:
             raise ValueError("datasets.train needs gt_size or lq_size for the OTF crop")
         if self.rng.uniform() < self.o["p_clean"]:
+            return dict(gt=gt, clean=True)
+        out = self._before_codec_stages(gt, kernel1, sinc_kernel)
+        host = self._pinned.get(tuple(out.shape))          # one pinned staging buffer per shape, reused (a fresh pinned allocation per step
+        if host is None:                                    # costs a host-side device synchronisation)
+            host = self._pinned[tuple(out.shape)] = torch.empty(out.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(gt=gt, clean=False, out=out, host=host, event=ev)
+
+    @torch.no_grad()
+    def finish(self, st: dict):
+        gt = st["gt"]
+        if st["clean"]:
             lq = gt.clone()
         else:
-            lq = self.degrade(gt, kernel1, sinc_kernel)
+            st["event"].synchronize()
+            lq = self._after_codec_stages(st["out"], st["host"])
         lq = clamp_round_u8(lq)
         # (the clean pass-through keeps GT resolution, so with scale > 1 the crop below raises "Scale mismatches" -- as the reference does)
         gt, lq = paired_random_crop(gt, lq, self.gt_size, self.scale, rnd=self.rnd)
