@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--otf", action="store_true", help="BASELINE.json configs[2] feed: RealESRGANModel -- every step's feed_data runs the on-the-fly degradation "
                                                        "stages (template values of options/_templates/train/ESRGAN/ESRGAN_OTF_gan.yml) on GT tiles + blur kernels")
     ap.add_argument("--fast-matmul", action="store_true", help="the reference's fast_matmul option: split-bf16 (3 bf16 MFMAs per product) for the fp32-forced VGG; NOT the default line")
+    ap.add_argument("--graphs", action="store_true", help="use_compile: true -> the generator's forward / backward replay as hipGraphs (helps the host-launch-bound "
+                                                          "small-tile configs; the per-launch roofline timers then see only the launches outside the graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational fast_matmul measurement")
     ap.add_argument("--no-roofline", action="store_true")
@@ -80,7 +82,7 @@ def make_opt(args):
                      resize_mode_prob3=[0.25, 0.25, 0.25, 0.25])
     return parse_options_dict(dict(
         **extra,
-        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, fast_matmul=args.fast_matmul, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
+        name="bench", scale=args.scale, num_gpu=1, path={}, manual_seed=1024, use_compile=args.graphs, fast_matmul=args.fast_matmul, use_amp=args.compute != "f32", amp_bf16=args.compute == "bf16",
         network_g=dict(type="esrgan", num_blocks=args.blocks) if args.arch == "esrgan" else dict(type=args.arch, scale=args.scale),
         datasets=dict(train=dict(name="synthetic", type="pairedimagedataset", lq_size=args.lq, batch_size_per_gpu=args.batch, accum_iter=1)),
         train=dict(total_iter=1000000, ema_decay=0.999, ema_power=0.75,
@@ -291,7 +293,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.compute, "data": "synthetic",
             "config": {"workload": (f"ESRGAN 4x (RRDBNet {args.blocks} blocks)" if args.arch == "esrgan" else f"{args.arch} {sc}x")
-                                   + f" {args.losses} {args.compute}" + (" +GAN(UNetDiscriminatorSN)" if args.gan else "") + (" +OTF feed (RealESRGANModel.feed_data per step, host codec round trip included)" if args.otf else "") + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
+                                   + f" {args.losses} {args.compute}" + (" +GAN(UNetDiscriminatorSN)" if args.gan else "") + (" +OTF feed (RealESRGANModel.feed_data per step, host codec round trip included)" if args.otf else "") + (" fast_matmul(split-bf16 VGG)" if args.fast_matmul else "") + (" hipGraph replay of G fwd/bwd" if args.graphs else "") + f", {s}->{sc * s} tiles, batch {n}/GPU, AdamW+EMA, optimize_parameters per step",
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }

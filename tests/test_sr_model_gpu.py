@@ -287,3 +287,33 @@ def test_mosr_step_matches_oracle(cuda):
     e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in params.items())
     print("mosr weights after one step", e_w)
     assert e_w < 5e-4
+
+
+@pytest.mark.parametrize("arch", [dict(type="esrgan", num_blocks=2), dict(type="span", feature_channels=16), dict(type="mosr_t", n_block=2, dim=32)])
+def test_hip_graph_replay_is_bit_identical_to_eager_steps(cuda, arch):
+    """`use_compile: true` = hipGraph replay of the generator's forward / backward (archs/_arena.py): six steps on changing batches give
+    bit-identical weights, EMA and logs to the eager trainer; a batch of another shape falls back to eager launches and re-captures."""
+    from trainner_redux_amd.models import SRModel
+    from trainner_redux_amd.utils.misc import set_random_seed
+
+    def run(graphs):
+        set_random_seed(3)
+        opt = _opt([dict(type="l1loss", loss_weight=1.0)], network_g=arch)
+        opt.use_compile = graphs
+        m = SRModel(opt)
+        logs = []
+        for it in range(1, 7):
+            lq, gt = _data(seed=100 + it, n=2, s=16 if it != 5 else 12)       # step 5: another tile size
+            m.feed_data({"lq": lq, "gt": gt})
+            m.optimize_parameters(it, 0, True)
+            logs.append(m.get_current_log()["l_g_l1"])
+        return m, logs
+
+    a, la = run(False)
+    b, lb = run(True)
+    assert b.net_g.hip_graphs and b.net_g._gs is not None and not a.net_g.hip_graphs
+    assert la == lb
+    for (k, va), vb in zip(a.net_g.state_dict().items(), b.net_g.state_dict().values()):
+        assert torch.equal(va, vb), k
+    for va, vb in zip(a.net_g_ema.ema_model.state_dict().values(), b.net_g_ema.ema_model.state_dict().values()):
+        assert torch.equal(va, vb)

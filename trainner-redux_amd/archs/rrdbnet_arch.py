@@ -183,6 +183,7 @@ class RRDBNet(FlatParamModule):
         dev, cdt = self._arena.device, self.compute_dtype
         nf, gc, nb = self.nf, self.gc, self.nb
         ws = _Workspace()
+        self._pool_epoch += 1       # new buffers: captured hipGraphs (archs/_arena.py) must not outlive the geometry they were recorded on
         e = lambda *s, dt=cdt: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731
         ws.x8 = e(n, h, w, 8 * ((self.in_nc + 7) // 8))
         nblk = 3 * nb
@@ -200,6 +201,7 @@ class RRDBNet(FlatParamModule):
     def _bwd_workspace(self, ws: _Workspace, n: int, h: int, w: int) -> None:
         if hasattr(ws, "G"):
             return
+        self._pool_epoch += 1
         dev, cdt = self._arena.device, self.compute_dtype
         nf, gc = self.nf, self.gc
         e = lambda *s, dt=cdt: torch.empty(*s, dtype=dt, device=dev)  # noqa: E731

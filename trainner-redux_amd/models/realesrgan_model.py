@@ -7,16 +7,17 @@ DataFeed contract (utils/types.py:10-17, data/realesrgan_dataset.py:213-219): tr
 Unlike the reference (hard-coded `.cuda()` on a DiffJPEG module it never calls, :81-83) nothing here is constructed that is not used.
 
 Overlap.  The compression stage is a host codec round trip (as in the reference), i.e. a device -> host -> device hop in the middle of
-the feed.  `prefetch(data)` runs only the FIRST half of a coming batch's feed (device stages + an async copy to pinned memory + an event) and
-the following `feed_data(data)` with the same batch object the second half (codec on the already-copied pixels, 8-bit rounding, crop,
-pool), so the hop waits on an event recorded a whole training step earlier.  Same thread, same stream, same RNG draw order.
-Measured (tools/time_otf_step.py, configs[2]: ESRGAN + VGG + UNet-D at batch 8 / 64 -> 256): that configuration is bound by the HOST --
-52.8 ms of GPU work per step against 58 ms to enqueue its ~1,600 launches from Python -- so the feed's 7-14 ms of codec time adds to the
-step whichever way it is scheduled (68 ms unsplit, 73 ms split; a worker thread on a side stream: 86 ms, it fights the training thread
-for the interpreter lock).  The split pays only where the step is GPU-bound; the cure for the launch-bound tiles is a recorded launch plan /
-hipGraph of forward_hip + backward_hip, not scheduling of the feed.
+the feed.  On the training stream that hop waits for everything queued before it -- the whole previous step -- and the GPU then idles while
+the host runs the codec and re-fills the launch queue: configs[2] (ESRGAN + VGG + UNet-D, batch 8, 64 -> 256; 52.8 ms of GPU work per
+step) measured 81 ms/step that way.  The feed therefore runs on its own high-priority HIP stream: its kernels and copies interleave with
+the previous step still executing on the training stream, the host waits only for that stream's few small kernels, and the training stream
+just waits on an event before it reads the new pair.  `prefetch(data)` additionally splits the feed so that the device half of the NEXT batch
+is issued before the current step (the codec then finds its pixels already in pinned memory).  Same thread, same RNG draw order.
+(A worker thread was measured slower: it fights the launch-bound training thread for the interpreter lock.)
 """
 from __future__ import annotations
+
+import torch
 
 from ..data.otf import OTFDegrader
 from .sr_model import SRModel
@@ -29,11 +30,18 @@ class RealESRGANModel(SRModel):
         self.queue_size = self.otf.pool.queue_size
         self.kernel1 = self.kernel2 = self.sinc_kernel = None
         self._otf_pending = None        # (id(data), state of OTFDegrader.start, kernels)
+        self._otf_stream = None
+
+    def _side(self):
+        if self._otf_stream is None:
+            self._otf_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return torch.cuda.stream(self._otf_stream)
 
     def _start(self, data: dict):
-        gt = self._to_device_f32(data["gt"])
-        ks = tuple(data[k].to(self.device, non_blocking=True) for k in ("kernel1", "kernel2", "sinc_kernel"))
-        return self.otf.start(gt, *ks), ks
+        with self._side():
+            gt = self._to_device_f32(data["gt"])
+            ks = tuple(data[k].to(self.device, non_blocking=True) for k in ("kernel1", "kernel2", "sinc_kernel"))
+            return self.otf.start(gt, *ks), ks
 
     def prefetch(self, data: dict) -> None:
         """Run the device half of a coming training batch's feed now; `feed_data(data)` (same object) finishes it."""
@@ -48,7 +56,13 @@ class RealESRGANModel(SRModel):
             if pend is not None and pend[0] != id(data):
                 raise RuntimeError("feed_data received a different batch than the one handed to prefetch()")
             st, ks = pend[1:] if pend is not None else self._start(data)
-            self.lq, self.gt = self.otf.finish(st)
+            with self._side():
+                lq, gt = self.otf.finish(st)
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self._otf_stream)
+            for t in (lq, gt, *ks):
+                t.record_stream(cur)          # allocated on the feed stream, read on the training stream
+            self.lq, self.gt = lq, gt
             self.kernel1, self.kernel2, self.sinc_kernel = ks
         else:
             super().feed_data(data)     # paired training or validation

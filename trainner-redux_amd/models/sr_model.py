@@ -99,6 +99,10 @@ class SRModel:
         self.net_g = build_network({**opt.network_g, "scale": opt.scale}).to(self.device)
         if hasattr(self.net_g, "compute_dtype"):
             self.net_g.compute_dtype = self.compute_dtype
+        if getattr(opt, "use_compile", False) and hasattr(self.net_g, "hip_graphs"):
+            # the reference's `use_compile` (torch.compile around the networks, base_model.py:214-226: spend warm-up time, run steps faster)
+            # maps onto hipGraph replay of the generator's forward / backward launches -- there is no tracing compiler on this path
+            self.net_g.hip_graphs = True
         self.net_d: nn.Module | None = None
         self.net_g_ema: EMA | None = None
         self.losses: "OrderedDict[str, nn.Module]" = OrderedDict()
@@ -258,9 +262,9 @@ class SRModel:
         if not self._pending:
             return
         torch.cuda.current_stream().synchronize()
-        for keys, vals, n in self._pending:
-            host = vals.tolist()
-            for k, v in zip(keys, host):
+        for keys, idx, vals, n in self._pending:
+            block = vals.tolist()
+            for k, v in zip(keys, (block[i] for i in idx)):
                 if k == "l_g_total" and not (v == v and abs(v) != float("inf")):
                     self._pending = []
                     raise RuntimeError("Training failed: NaN/Inf found in loss.")
@@ -296,7 +300,7 @@ class SRModel:
         gt = gt.contiguous()
 
         if hip_net:
-            out = net.forward_hip(lq, train=True)
+            out = net.train_forward(lq) if hasattr(net, "train_forward") else net.forward_hip(lq, train=True)
             out_leaf = None
         else:  # foreign generator (stock nn.Module from the open plugin surface): ordinary autograd
             with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
@@ -378,7 +382,10 @@ class SRModel:
         keys.append("l_g_total")
 
         if hip_net:
-            net.backward_hip(gout)
+            if hasattr(net, "train_backward"):
+                net.train_backward(gout)
+            else:
+                net.backward_hip(gout)
 
         rank, world = get_dist_info()
         if apply_gradient:
@@ -516,8 +523,10 @@ class SRModel:
             if apply_gradient and len(self.optimizers_skipped) > 1 and not (hasattr(self.net_d, "forward_hip") and hasattr(cri_gan, "hip_value_and_grad")):
                 self.optimizers_skipped[-1] = False
 
-        # device-resident log values of this step; read back lazily by get_current_log()
-        self._pending.append((keys, scal[idx], n_samples))
+        # device-resident log values of this step; read back lazily by get_current_log().  The whole 64-float block is cloned on the stream
+        # and indexed on the host at read-back: `scal[idx]` with a Python list uploads an index tensor, i.e. a synchronous host -> device copy
+        # that drained the launch queue at the end of EVERY step (found with torch.cuda.set_sync_debug_mode, tools/find_sync.py)
+        self._pending.append((keys, idx, scal.clone(), n_samples))
         if len(self._pending) >= 64:
             self._flush_pending()
 

@@ -59,7 +59,22 @@ class AdamW(torch.optim.Optimizer):
         self._ema_arena, self._ema_decay, self._clip, self._grad_norm, self._inv_scale = ema_arena, ema_decay, clip, grad_norm, inv_scale
 
     def _group_arenas(self, group):
-        """Split a param group into arenas (fused) and loose tensors."""
+        """Split a param group into arenas (fused) and loose tensors.  The split is cached per group under a cheap signature (count,
+        storage pointers of the first / last parameter and gradient, number of absent gradients): walking 700 parameters through
+        `_arena_of` cost 16 ms of host time per step() on ESRGAN -- a third of the step at the launch-bound tile sizes."""
+        ps = group["params"]
+        first, last = ps[0], ps[-1]
+        sig = (len(ps), first.data_ptr(), last.data_ptr(), first.grad.data_ptr() if first.grad is not None else 0,
+               last.grad.data_ptr() if last.grad is not None else 0, sum(1 for p in ps if p.grad is None))
+        cache = self.__dict__.setdefault("_group_cache", {})
+        hit = cache.get(id(group))
+        if hit is not None and hit[0] == sig:
+            return hit[1], list(hit[2])
+        arenas, loose = self._group_arenas_uncached(group)
+        cache[id(group)] = (sig, arenas, tuple(loose))
+        return arenas, list(loose)
+
+    def _group_arenas_uncached(self, group):
         arenas: dict = defaultdict(list)
         loose = []
         for p in group["params"]:
