@@ -107,6 +107,15 @@ typedef struct tr_conv3x3_desc {
 
 int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
 
+/* The same convolution (3x3, pad 1, zero padding, fp32 views, cin % 8 == 0, cout % 64 == 0, even h and w; bias, ReLU and the sign mask of the
+ * epilogue only) as a fused Winograd F(2x2, 3x3) kernel in exact fp32 arithmetic: 2.25x fewer MFMA cycles than the direct form for the
+ * fp32-forced VGG19 perceptual head (losses/perceptual_loss.py:8-12, perceptual_fp16_loss.py:262-329).  `wpacked` comes from
+ * tr_pack_winograd (U = G g G^T per (cout, cin) pair; transpose != 0 packs the input-gradient conv of an OIHW weight, i.e. cout / cin name
+ * the channels of THIS launch's output / input).  d->compute is ignored.  Differs from tr_conv3x3 by fp32 rounding only (~1e-6). */
+size_t tr_winograd_packed_bytes(int cin, int cout);
+int    tr_pack_winograd(void* stream, const float* w_oihw, float* dst, int cout, int cin, int transpose);
+int    tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d);
+
 /* Gradient of a <=4-channel stem conv (VGG19 conv1_1, perceptual_fp16_loss.py:272-274) with respect to the NCHW fp32
  * image: conv_backward_input + adjoint of zero/replicate padding + per-channel scale (1/std of the input
  * normalisation, host pointer, may be NULL); dst (+)= result.  Weights are the fp32 OIHW master tensor. */
