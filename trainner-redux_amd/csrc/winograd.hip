@@ -6,31 +6,37 @@
 // written and read on both sides of the GEMMs): here V = B^T d B is computed by the loader threads on the way into LDS and the 16
 // products M_xi leave the accumulators only through LDS, so HBM sees the input once per output-channel group and the output once.
 //
-// Workgroup = 256 threads = 4 waves; tile = 64 output channels x 32 Winograd tiles (4 x 8 tiles = 8 x 16 output pixels).
-// K loop over 8-channel chunks.  Per chunk:
+// Workgroup = 512 threads = 8 waves, one per CU; tile = 64 output channels x 64 Winograd tiles (8 x 8 tiles = 16 x 16 output pixels).
+// K loop over 8-channel chunks, two LDS stages (2 x 64 KB), ONE barrier per chunk.  Per chunk:
 //   * loader role (thread = (tile, channel)): 16 scalar loads of the 4 x 4 patch (8 lanes = 32 contiguous bytes of a pixel record), issued
-//     one chunk ahead; B^T d B in registers (32 adds); the 16 values go to the 16 xi-planes of LDS in B-operand order [xi][kk][tile][s]
-//     (channel c = 2 s + kk, the K pairing of v_mfma_f32_32x32x2_f32); the pre-transformed weights U (packed [group][chunk][xi][kk][k][s]
-//     by tr_pack_winograd) are copied straight into LDS: 32 KB, 8 x 16 B per thread.
-//   * MFMA role: wave j owns the four positions xi = (i, j), i = 0..3: per position 1 B fragment + 2 A fragments (ds_read_b128, conflict
-//     free) feed 8 MFMAs; 32 MFMAs per wave and chunk.
-// Epilogue: wave j folds its column in registers, T_j = A^T M[:, j] (2 x 16 adds on accumulator tiles of identical layout), the four
+//     one chunk ahead; B^T d B in registers (32 adds); the 16 values go to the 16 xi-planes of the NEXT stage in B-operand order
+//     [xi][kk][tile][s] (channel c = 2 s + kk, the K pairing of v_mfma_f32_32x32x2_f32); the pre-transformed weights U (packed
+//     [group][chunk][xi][kk][k][s] by tr_pack_winograd) are copied straight into LDS: 32 KB, 4 x 16 B per thread.
+//   * MFMA role: wave (j, half) owns the four positions xi = (i, j), i = 0..3, for 32 of the 64 tiles: per position 1 B fragment + 2 A
+//     fragments (ds_read_b128, conflict free) feed 8 MFMAs; 32 MFMAs per wave and chunk.  Waves drift apart between barriers, so one wave's
+//     stage writes overlap another's MFMAs.
+// The first version (256 threads, 32 tiles, one stage, two workgroups per CU) reached 160-208 TFLOP/s effective and was bound by the
+// L2 -> LDS traffic of U (32 KB per 32 tiles and chunk: ~20 TB/s chip-wide at full MFMA rate); 64 tiles per staged U halve it.
+// Epilogue: wave (j, half) folds its column in registers, T_j = A^T M[:, j] (2 x 16 adds on accumulator tiles of identical layout), the
 // waves exchange T through LDS ([j][r][tile][36-float rows]: b128 writes and b32 reads conflict free), and every thread finishes
 // Y[r][:] = T[r] A for its (channel, tile) pairs with bias / ReLU / ReLU-derivative mask, storing 128 contiguous bytes per pixel and wave half.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int W_TB = 32;                      // tiles per workgroup (4 rows x 8 cols)
+constexpr int W_TB = 64;                      // tiles per workgroup (8 rows x 8 cols)
 constexpr int W_KB = 64;                      // output channels per workgroup
 constexpr int W_CK = 8;                       // input channels per chunk
+constexpr int W_THREADS = 512;
 constexpr int U_FLOATS = 16 * 2 * W_KB * 4;   // 8192 floats = 32 KB per (group, chunk)
-constexpr int V_FLOATS = 16 * 2 * W_TB * 4;   // 4096 floats = 16 KB
+constexpr int V_FLOATS = 16 * 2 * W_TB * 4;   // 8192 floats = 32 KB
+constexpr int STAGE_FLOATS = U_FLOATS + V_FLOATS;
 constexpr int T_STRIDE = 36;                  // floats per (j, r, tile) row of the exchange buffer (32 + 4: b128-aligned, conflict free)
-constexpr int SMEM_BYTES = (U_FLOATS + V_FLOATS) * 4;   // 48 KB (the exchange buffer, 4*2*32*36*4 = 36,864 B, reuses it)
+constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;        // 128 KB (the exchange buffer, 4*2*64*36*4 = 73,728 B, reuses it)
 
 struct WinoArgs {
     int n, h, w, cin, cout;
@@ -42,12 +48,12 @@ struct WinoArgs {
     int nty, ntx, nchunks, nkg;
 };
 
-__global__ __launch_bounds__(256, 2) void winograd_f32_kernel(WinoArgs a) {
+__global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ul = (float*)smem;
-    float* vl = ul + U_FLOATS;
+    float* stage = (float*)smem;
     const int tid = threadIdx.x;
     const int l = tid & 63, wv = tid >> 6, lr = l & 31, lh = l >> 5;
+    const int wj = wv & 3, wth = wv >> 2;       // Winograd column of this wave, and its half of the 64 tiles
     int b = blockIdx.x;
     const int kg = b % a.nkg; b /= a.nkg;      // output-channel group fastest: neighbours in the grid share the input tile in L2
     const int bx = b % a.ntx; b /= a.ntx;
@@ -56,28 +62,63 @@ __global__ __launch_bounds__(256, 2) void winograd_f32_kernel(WinoArgs a) {
 
     // ---- loader role: channel lc of the chunk, tile lt of the workgroup ---------------------------------------------------------------
     const int lc = tid & 7, lt = tid >> 3;
-    const int py0 = 2 * (by * 4 + (lt >> 3)) - 1, px0 = 2 * (bx * 8 + (lt & 7)) - 1;     // top-left pixel of the 4 x 4 input patch (pad 1)
+    const int py0 = 2 * (by * 8 + (lt >> 3)) - 1, px0 = 2 * (bx * 8 + (lt & 7)) - 1;     // top-left pixel of the 4 x 4 input patch (pad 1)
+    // Branch-free patch loads: every load goes out unconditionally from a clamped address and padding is a select afterwards.  (Guarding
+    // each load with its own condition made the compiler put it in its own basic block: 183 branches in the kernel, loads serialised
+    // behind waits, and no overlap at all between the loader work and the MFMAs.)
     unsigned okmask = 0;
+    int yo[4], xo[4];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        const int y = py0 + (p >> 2), x = px0 + (p & 3);
-        if (y >= 0 && y < a.h && x >= 0 && x < a.w) okmask |= 1u << p;
+    for (int r = 0; r < 4; ++r) {
+        const int y = py0 + r, x = px0 + r;
+        if (y >= 0 && y < a.h) okmask |= 0xFu << (4 * r);
+        yo[r] = min(max(y, 0), a.h - 1) * (a.w * a.in.cstride);
+        xo[r] = min(max(x, 0), a.w - 1) * a.in.cstride;
+    }
+    {
+        unsigned cm = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (px0 + c >= 0 && px0 + c < a.w) cm |= 0x1111u << c;
+        okmask &= cm;
     }
     const float* inb = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff + lc;
-    const int rowp = a.w * a.in.cstride, colp = a.in.cstride;
-    const int off0 = py0 * rowp + px0 * colp;                                            // may be negative: guarded by okmask
     const f32x4* ub = (const f32x4*)(a.u + (int64_t)kg * a.nchunks * U_FLOATS) + tid;
     float d[16];
-    f32x4 ureg[8];
-    auto issue = [&](int ch) {
-        const float* src = inb + ch * W_CK;
+    f32x4 ureg[4];
+    auto issue = [&](int ch) {                   // ch may run past the last chunk (clamped: a redundant load instead of a branch)
+        const int chc = min(ch, a.nchunks - 1);
+        const float* src = inb + chc * W_CK;
 #pragma unroll
-        for (int p = 0; p < 16; ++p) d[p] = ((okmask >> p) & 1u) ? src[off0 + (p >> 2) * rowp + (p & 3) * colp] : 0.f;
-        const f32x4* us = ub + (int64_t)ch * (U_FLOATS / 4);
+        for (int p = 0; p < 16; ++p) d[p] = src[yo[p >> 2] + xo[p & 3]];
+        const f32x4* us = ub + (int64_t)chc * (U_FLOATS / 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ureg[j] = us[j * 256];
+        for (int j = 0; j < 4; ++j) ureg[j] = us[j * W_THREADS];
     };
-    float* vdst = vl + ((lc & 1) * W_TB + lt) * 4 + (lc >> 1);                           // + xi * 256 floats
+    const int voff = U_FLOATS + ((lc & 1) * W_TB + lt) * 4 + (lc >> 1);                  // + xi * 512 floats within a stage
+    auto fill = [&](float* st) {                 // registers of the prefetched chunk -> one LDS stage
+        // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        float t[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) d[p] = ((okmask >> p) & 1u) ? d[p] : 0.f;       // zero padding
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            t[0 + x] = d[0 + x] - d[8 + x];
+            t[4 + x] = d[4 + x] + d[8 + x];
+            t[8 + x] = d[8 + x] - d[4 + x];
+            t[12 + x] = d[4 + x] - d[12 + x];
+        }
+        float* vdst = st + voff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vdst[(i * 4 + 0) * 512] = t[i * 4 + 0] - t[i * 4 + 2];
+            vdst[(i * 4 + 1) * 512] = t[i * 4 + 1] + t[i * 4 + 2];
+            vdst[(i * 4 + 2) * 512] = t[i * 4 + 2] - t[i * 4 + 1];
+            vdst[(i * 4 + 3) * 512] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ((f32x4*)st)[tid + j * W_THREADS] = ureg[j];
+    };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -86,72 +127,71 @@ __global__ __launch_bounds__(256, 2) void winograd_f32_kernel(WinoArgs a) {
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][kh][e] = 0.f;
-
-    issue(0);
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        __syncthreads();                                   // every wave has consumed the previous chunk's operands
-        {
-            // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-            float t[16];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                t[0 + x] = d[0 + x] - d[8 + x];
-                t[4 + x] = d[4 + x] + d[8 + x];
-                t[8 + x] = d[8 + x] - d[4 + x];
-                t[12 + x] = d[4 + x] - d[12 + x];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vdst[(i * 4 + 0) * 256] = t[i * 4 + 0] - t[i * 4 + 2];
-                vdst[(i * 4 + 1) * 256] = t[i * 4 + 1] + t[i * 4 + 2];
-                vdst[(i * 4 + 2) * 256] = t[i * 4 + 2] - t[i * 4 + 1];
-                vdst[(i * 4 + 3) * 256] = t[i * 4 + 1] - t[i * 4 + 3];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ((f32x4*)ul)[tid + j * 256] = ureg[j];
-        }
-        __syncthreads();
-        if (ch + 1 < a.nchunks) issue(ch + 1);             // next chunk in flight behind this chunk's MFMAs
+    // 4 steps (position i) of 8 MFMAs; the two channel halves alternate so that consecutive MFMAs never accumulate into the same tile, and
+    // the operand fragments of step i + 1 are read from LDS before the MFMAs of step i issue (a fresh ds_read in front of every group cost
+    // its full latency, ~100+ cycles under the fill traffic, per 256 cycles of MFMAs)
+    auto mfmas = [&](const float* ul, const float* vl) {
+        const float* ua = ul + (lh * W_KB + lr) * 4;
+        const float* vb = vl + (lh * W_TB + wth * 32 + lr) * 4;
+        f32x4 bv[2], au[2][2];
+        bv[0] = *(const f32x4*)(vb + wj * 512);
+        au[0][0] = *(const f32x4*)(ua + wj * 512);
+        au[0][1] = *(const f32x4*)(ua + wj * 512 + 128);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int xi = i * 4 + wv;
-            const f32x4 bv = *(const f32x4*)(vl + xi * 256 + (lh * W_TB + lr) * 4);
-#pragma unroll
-            for (int kh = 0; kh < 2; ++kh) {
-                const f32x4 au = *(const f32x4*)(ul + xi * 512 + (lh * W_KB + kh * 32 + lr) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][kh] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[e], bv[e], acc[i][kh], 0, 0, 0);
+            if (i + 1 < 4) {
+                const int xi2 = (i + 1) * 4 + wj;
+                bv[(i + 1) & 1] = *(const f32x4*)(vb + xi2 * 512);
+                au[(i + 1) & 1][0] = *(const f32x4*)(ua + xi2 * 512);
+                au[(i + 1) & 1][1] = *(const f32x4*)(ua + xi2 * 512 + 128);
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[i & 1][0][e], bv[i & 1][e], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[i & 1][1][e], bv[i & 1][e], acc[i][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    issue(0);
+    fill(stage);
+    issue(1);
+    __syncthreads();
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const float* ul = stage + (ch & 1) * STAGE_FLOATS;
+        // straight-line body: the fill after the last chunk writes a stage nobody reads, the loads past the end re-read the last chunk
+        fill(stage + ((ch + 1) & 1) * STAGE_FLOATS);       // the other stage was released by the barrier that ended the previous iteration
+        issue(ch + 2);                                     // two chunks ahead of the MFMAs below
+        mfmas(ul, ul + U_FLOATS);
+        __syncthreads();                                   // this stage consumed by every wave, the other stage completely written
     }
 
     // ---- output transform + epilogue, one 32-channel half at a time ------------------------------------------------------------------------
     float* tl = (float*)smem;
     const int ek = tid & 31, etg = tid >> 5;
-    const float* ob = nullptr;
-    (void)ob;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-        __syncthreads();                                   // LDS free (operands of the last chunk / the previous half's exchange)
+        if (kh) __syncthreads();                           // the previous half's exchange has been read
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t0, t1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float m0 = acc[0][kh][q * 4 + e], m1 = acc[1][kh][q * 4 + e], m2 = acc[2][kh][q * 4 + e], m3 = acc[3][kh][q * 4 + e];
-                t0[e] = m0 + m1 + m2;                      // A^T = [1 1 1 0; 0 1 -1 -1] applied down column j = wv
+                t0[e] = m0 + m1 + m2;                      // A^T = [1 1 1 0; 0 1 -1 -1] applied down column j
                 t1[e] = m1 - m2 - m3;
             }
-            *(f32x4*)(tl + ((wv * 2 + 0) * W_TB + lr) * T_STRIDE + q * 8 + lh * 4) = t0;
-            *(f32x4*)(tl + ((wv * 2 + 1) * W_TB + lr) * T_STRIDE + q * 8 + lh * 4) = t1;
+            *(f32x4*)(tl + ((wj * 2 + 0) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t0;
+            *(f32x4*)(tl + ((wj * 2 + 1) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t1;
         }
         __syncthreads();
         const int kc = kg * W_KB + kh * 32 + ek;
         const float bias = a.bias ? a.bias[kc] : 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int t = etg + 8 * i;
-            const int ty = by * 4 + (t >> 3), tx = bx * 8 + (t & 7);
+            const int t = etg + 16 * i;
+            const int ty = by * 8 + (t >> 3), tx = bx * 8 + (t & 7);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const float T0 = tl[((0 * 2 + r) * W_TB + t) * T_STRIDE + ek], T1 = tl[((1 * 2 + r) * W_TB + t) * T_STRIDE + ek];
@@ -242,10 +282,12 @@ extern "C" int tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d) {
     a.act = d->act; a.mask_slope = d->mask_slope;
     a.in = d->in; a.out = d->out; a.mask = d->mask;
     a.u = (const float*)d->wpacked; a.bias = d->bias;
-    a.nty = (d->h / 2 + 3) / 4; a.ntx = (d->w / 2 + 7) / 8;
+    a.nty = (d->h / 2 + 7) / 8; a.ntx = (d->w / 2 + 7) / 8;
     a.nchunks = d->cin / W_CK; a.nkg = d->cout / W_KB;
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: grid too large");
-    hipLaunchKernelGGL(winograd_f32_kernel, dim3((unsigned)nblk), dim3(256), SMEM_BYTES, (hipStream_t)stream, a);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)winograd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+    TR_REQUIRE(attr == hipSuccess, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: the device does not grant %d bytes of LDS per workgroup", SMEM_BYTES);
+    hipLaunchKernelGGL(winograd_f32_kernel, dim3((unsigned)nblk), dim3(W_THREADS), SMEM_BYTES, (hipStream_t)stream, a);
     return tr::launch_status("tr_conv3x3_winograd_f32");
 }

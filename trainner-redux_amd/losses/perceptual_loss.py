@@ -99,6 +99,9 @@ class VGG(nn.Module):
         self._build_program()
         self._packs = None
         self._ws: dict = {}
+        # exact-fp32 convs run as fused Winograd F(2x2, 3x3) MFMA kernels (same arithmetic type, 2.25x fewer multiplies, ~1e-6 from the
+        # direct sum); TRAINNER_VGG_WINOGRAD=0 keeps the direct kernel
+        self.winograd = os.environ.get("TRAINNER_VGG_WINOGRAD", "1") != "0"
 
     # -- weights ------------------------------------------------------------------------------------------
     def init_synthetic(self, seed: int = 0) -> None:
@@ -183,6 +186,10 @@ class VGG(nn.Module):
             b = torch.zeros(ops.packed_bytes(m.cout, m.cin, cd), dtype=torch.uint8, device=dev)
             plan.add(m.weight.data, b, m.cout, m.cin, cd, transpose=True)
             pk[name] = (f, b)
+            if cd == L.F32 and self.winograd and k > 0 and m.cin % 8 == 0 and m.cout % 64 == 0 and m.cin % 64 == 0:
+                # exact-fp32 mode: the fused Winograd F(2x2, 3x3) kernel (csrc/winograd.hip) for every conv but the replicate-padded stem;
+                # forward slab and the slab of the input-gradient conv (VGG weights are frozen: packed once)
+                pk[name] = (f, b, ops.pack_winograd(m.weight.data), ops.pack_winograd(m.weight.data, transpose=True))
         plan.finalize().run()
         self._packs = ((cd, str(dev)), pk, plan)
         return pk
@@ -233,8 +240,9 @@ class VGG(nn.Module):
                 else:
                     out = ws["scratch"][flip].view(-1)[: n * hh * ww * m.cout].view(n, hh, ww, m.cout)
                     flip ^= 1
-                ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=cd, inp=V(cur, 0, cur_c), out=V(out), wpacked=pk[name][0],
-                            bias=m.bias.data, act=L.ACT_RELU if fused_relu else L.ACT_NONE,
+                wino = len(pk[name]) > 2 and not first and hh % 2 == 0 and ww % 2 == 0
+                ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD if wino else cd, inp=V(cur, 0, cur_c), out=V(out),
+                            wpacked=pk[name][2 if wino else 0], bias=m.bias.data, act=L.ACT_RELU if fused_relu else L.ACT_NONE,
                             pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
                 first = False
                 cur, cur_c = out, m.cout
@@ -319,8 +327,9 @@ class VGG(nn.Module):
             dst_buf = pool_pair[1] if g.data_ptr() == pool_pair[0].data_ptr() else pool_pair[0]
             gin = dst_buf.view(-1)[: inp_act.numel()].view(inp_act.shape)
             mask = V(inp_act) if (prev[0] == "conv" and prev[3]) else ops.NULL_VIEW
-            ops.conv3x3(n=n, h=hh, w=ww, cin=m.cout, cout=m.cin, compute=cd, inp=V(g), out=V(gin), wpacked=pk[name][1], mask=mask,
-                        mask_slope=0.0)
+            wino = len(pk[name]) > 2 and hh % 2 == 0 and ww % 2 == 0
+            ops.conv3x3(n=n, h=hh, w=ww, cin=m.cout, cout=m.cin, compute=L.F32_WINOGRAD if wino else cd, inp=V(g), out=V(gin),
+                        wpacked=pk[name][3 if wino else 1], mask=mask, mask_slope=0.0)
             g = gin
         return names
 
