@@ -9,7 +9,7 @@ A "step" = one full `optimize_parameters` call on one resident batch; value = gl
 Weak scaling: per-GPU batch is fixed; gradients are exchanged with ONE RCCL all-reduce of the flat gradient arena.
 
 The JSON line also carries
-  roofline     -- dominant kernel (the bf16 MFMA 3x3 conv): algorithmic FLOPs per launch / its average launch
+  roofline     -- dominant kernel (the fp32 VGG convs, run as fused Winograd MFMA kernels): algorithmic FLOPs per launch / its average launch
                   duration, measured live with HIP events on the launch stream during the timed region;
   cpu_baseline -- the oracle's step (pure PyTorch fp32, the reference's CPU path) timed on this host on a bounded
                   sample and scaled to the same unit.
@@ -111,7 +111,7 @@ class ConvTimer:
             e0.record()
             orig(**kw)
             e1.record()
-            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32"
+            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32"
             ks = kw.get("ksize", 3)
             flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * ks * ks * kw["cin"] * kw["cout"]
             timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1))
@@ -301,19 +301,24 @@ def main():
             agg = timer.summary()
             key = max(agg, key=lambda k: agg[k][2])
             cnt, flops, msum = agg[key]
-            peak = 157.3 if key[0] == "f32" else 2500.0
+            peak = 157.3 if key[0] in ("f32", "f32w") else 2500.0
             ach = flops / (msum * 1e-3) / 1e12
             traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 if args.arch == "esrgan" and tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
-                    traffic = tj[f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"] if key[2] == 3 else None
+                    traffic = tj["f32/winograd" if key[0] == "f32w" else f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"] if key[2] == 3 else None
             except Exception:
                 traffic = None
-            out["roofline"] = {"bound": "mfma", "kernel": f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}, ksize {key[2]}>", "achieved": ach, "peak": peak,
+            kname = "winograd_f32_kernel (fused Winograd F(2x2,3x3), exact fp32 MFMA)" if key[0] == "f32w" else f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}, ksize {key[2]}>"
+            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops / cnt, "launches": cnt,
                                "avg_launch_ms": msum / cnt,
                                "share_of_step": msum / (dt * 1e3),
+                               **({"mfma_executed_tflops": ach / 2.25, "mfma_executed_frac": ach / 2.25 / peak,
+                                   "note": "achieved / frac count the ALGORITHMIC FLOPs of the 3x3 convolution (2*9*Cin*Cout per pixel, DESIGN.md section 4); the "
+                                           "Winograd kernel executes 1/2.25 of those multiplies on the MFMA units (mfma_executed_*), which is how a frac above "
+                                           "the direct-convolution roofline is reached in exact fp32"} if key[0] == "f32w" else {}),
                                "all": {f"{k[0]}/cg{k[1]}" + ("" if k[2] == 3 else f"/k{k[2]}"): {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
         if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
             # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the

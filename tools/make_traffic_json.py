@@ -13,10 +13,13 @@ out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01
 groups = {}
 for k in fe:
     m = re.search(r"conv3x3_kernel_reg<(\d), (\d), (\d), 3>", k)
-    if not m:
+    if "winograd_f32_kernel" in k:
+        key = "f32/winograd"
+    elif not m:
         continue
-    ct, nt = int(m.group(1)), int(m.group(2))
-    key = ("f32" if ct == 0 else "bf16" if ct == 1 else "f16") + ("/cg64" if nt == 2 else "/cg32")
+    else:
+        ct, nt = int(m.group(1)), int(m.group(2))
+        key = ("f32" if ct == 0 else "bf16" if ct == 1 else "f16") + ("/cg64" if nt == 2 else "/cg32")
     g = groups.setdefault(key, [0, 0.0, 0.0])
     g[0] += fe[k][0]
     g[1] += fe[k][1]

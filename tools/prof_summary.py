@@ -7,7 +7,7 @@ def short(n):
     return n[:80]
 
 def kernel_stats(d):
-    f = glob.glob(f"{d}/*/*kernel_stats.csv")[0]
+    f = (glob.glob(f"{d}/*/*kernel_stats.csv") + glob.glob(f"{d}/*kernel_stats.csv"))[0]
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     out = [f"total GPU kernel time {tot / 1e6:.1f} ms", f"{'kernel':80s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}"]
@@ -16,7 +16,7 @@ def kernel_stats(d):
     return "\n".join(out)
 
 def pmc(d, counter):
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -29,7 +29,7 @@ def pmc(d, counter):
 
 def pmc_all(d):
     """every counter of a --pmc pass, averaged per (kernel, grid size, LDS bytes)"""
-    f = glob.glob(f"{d}/*/*counter_collection.csv")[0]
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
