@@ -164,7 +164,9 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
         fill(stage + ((ch + 1) & 1) * STAGE_FLOATS);       // the other stage was released by the barrier that ended the previous iteration
         issue(ch + 2);                                     // two chunks ahead of the MFMAs below
         mfmas(ul, ul + U_FLOATS);
-        __syncthreads();                                   // this stage consumed by every wave, the other stage completely written
+        // barrier on the LDS traffic only (__syncthreads() would also drain the global loads just issued for chunk ch + 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // this stage consumed by every wave, the other stage completely written
     }
 
     // ---- output transform + epilogue, one 32-channel half at a time ------------------------------------------------------------------------
