@@ -403,6 +403,10 @@ int tr_axpby_clamp01(void* stream, const float* a, float wa, const float* b, flo
  *   mode 2 chromatic aberration (realesrgan_model.py:244-311; params[ch] = affine scale of channel ch, 1 = untouched; zero padding, clamp to [0, 1]). */
 int tr_warp_bilinear(void* stream, const float* src, float* dst, int n, int c, int h, int w, int mode, const float* params_host);
 
+/* ---- input / output pixel formats (sr_model.py:471-481, utils/color_util.py:237-324): BT.601 conversions of fp32 NCHW 3-channel batches.
+ * mode 0 = rgb2ycbcr_pt, 1 = ycbcr2rgb_pt, 2 = adjoint of 1 (gradient of the loss w.r.t. a YCbCr network output given d/d(RGB)). */
+int tr_color601(void* stream, const float* src, float* dst, int n, int64_t hw, int mode);
+
 #ifdef __cplusplus
 }
 #endif

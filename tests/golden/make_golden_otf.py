@@ -7,6 +7,7 @@ same numpy Generator semantics (utils/rng.py:7-25) -- and only input / output ar
   kernels      random_mixed_kernels for every kernel type x 3 sizes under seeded numpy / python RNGs (with and without kernel noise),
                circular_lowpass_kernel (padded and not)
   resize       resize_pt for bilinear / bicubic / nearest-exact / lanczos on seeded images (size= and scale_factor= forms)
+  color        utils/color_util.py rgb2pixelformat_pt / pixelformat2rgb_pt / ycbcr2rgb_pt for "yuv444" (BT.601)
 """
 import importlib.util
 import math
@@ -69,7 +70,16 @@ def main():
                            ("mixed", (1, 3, 40, 40), dict(size=(40, 17))), ("factor", (1, 3, 30, 42), dict(scale_factor=0.4))):
         img = torch.rand(*shape, generator=g)
         resize[tag] = dict(img=img, kw=kw, out={m: D.resize_pt(img, mode=m, **kw) for m in ("bilinear", "bicubic", "nearest-exact", "lanczos")})
-    torch.save(dict(kernels=kernels, mixed=dict(seed=7, kernels=mixed), sinc=sinc, resize=resize), os.path.join(OUT, "otf_degradations.pt"))
+    # utils/color_util.py (needs only the PixelFormat name from utils/types.py, which wants Python 3.11: a stub carries it)
+    _stub("traiNNer.utils.types").PixelFormat = str
+    spec = importlib.util.spec_from_file_location("traiNNer.utils.color_util", os.path.join(REF, "traiNNer/utils/color_util.py"))
+    CU = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(CU)
+    rgb = torch.rand(2, 3, 13, 17, generator=g)
+    ycc = CU.rgb2pixelformat_pt(rgb, "yuv444")
+    color = dict(rgb=rgb, ycbcr=ycc, back=CU.pixelformat2rgb_pt(ycc, None, "yuv444"), any_ycbcr=torch.rand(2, 3, 13, 17, generator=g))
+    color["any_rgb"] = CU.ycbcr2rgb_pt(color["any_ycbcr"])
+    torch.save(dict(kernels=kernels, mixed=dict(seed=7, kernels=mixed), sinc=sinc, resize=resize, color=color), os.path.join(OUT, "otf_degradations.pt"))
     print("wrote otf_degradations.pt", len(kernels), "kernels")
 
 

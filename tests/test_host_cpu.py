@@ -253,7 +253,7 @@ def test_mfma_kernels_keep_accumulators_in_registers():
 
     B.build(verbose=False)
     res = json.load(open(B.RESOURCES))
-    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn", "dwconv"))}
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn", "dwconv", "winograd_f32"))}
     assert len(hot) >= 20
     bad = {k: v["scratch"] for k, v in hot.items() if v.get("scratch", 0) != 0 or v.get("vgpr_spill", 0) != 0}
     assert not bad, bad

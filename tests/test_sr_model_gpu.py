@@ -317,3 +317,49 @@ def test_hip_graph_replay_is_bit_identical_to_eager_steps(cuda, arch):
         assert torch.equal(va, vb), k
     for va, vb in zip(a.net_g_ema.ema_model.state_dict().values(), b.net_g_ema.ema_model.state_dict().values()):
         assert torch.equal(va, vb)
+
+
+def test_yuv444_pixel_format_matches_reference_colour_functions_and_trains(cuda):
+    """`input_pixel_format` / `output_pixel_format: yuv444` (sr_model.py:471-481): the BT.601 kernels against the reference's OWN
+    utils/color_util.py outputs (tests/golden/otf_degradations.pt), the adjoint against autograd, and one trainer step against the oracle
+    step with the conversions wrapped around the generator."""
+    from oracle import esrgan as OE, losses as OL, step as OS
+    from trainner_redux_amd import ops
+    from trainner_redux_amd.models import SRModel
+
+    c = torch.load(os.path.join(os.path.dirname(__file__), "golden", "otf_degradations.pt"), weights_only=True)["color"]
+    assert (ops.color601(c["rgb"].to(cuda), 0).cpu() - c["ycbcr"]).abs().max() < 2e-7
+    assert (ops.color601(c["any_ycbcr"].to(cuda), 1).cpu() - c["any_rgb"]).abs().max() < 1e-6
+    assert (ops.color601(c["ycbcr"].to(cuda), 1).cpu() - c["back"]).abs().max() < 1e-6
+
+    def rgb2ycc(x):
+        w = torch.tensor([[65.481, -37.797, 112.0], [128.553, -74.203, -93.786], [24.966, 112.0, -18.214]])
+        return (torch.matmul(x.permute(0, 2, 3, 1), w).permute(0, 3, 1, 2) + torch.tensor([16.0, 128.0, 128.0]).view(1, 3, 1, 1)) / 255.0
+
+    def ycc2rgb(x):
+        y, cb, cr = (x * 255.0).split(1, 1)
+        return torch.cat((1.164 * (y - 16) + 1.596 * (cr - 128), 1.164 * (y - 16) - 0.392 * (cb - 128) - 0.813 * (cr - 128),
+                          1.164 * (y - 16) + 2.017 * (cb - 128)), 1) / 255.0
+
+    v = c["any_ycbcr"].clone().requires_grad_(True)
+    gr = torch.randn(v.shape, generator=torch.Generator().manual_seed(1))
+    ycc2rgb(v).backward(gr)
+    assert (ops.color601(gr.to(cuda), 2).cpu() - v.grad).abs().max() < 1e-6
+    with pytest.raises(NotImplementedError):
+        o = _opt([dict(type="l1loss", loss_weight=1.0)]); o.input_pixel_format = "y"; SRModel(o)
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)])
+    opt.input_pixel_format = opt.output_pixel_format = "yuv444"
+    model = SRModel(opt)
+    hp = OE.esrgan_hparams(scale=4, num_blocks=2)
+    sd = {k: v.detach().cpu().clone() for k, v in model.net_g.state_dict().items()}
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    lq, gt = _data(seed=9)
+    _, ld, _, _ = OS.generator_step(params, lambda p, x: ycc2rgb(OE.forward(p, rgb2ycc(x), hp)), OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, None)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 1e-5 * float(ld["l_g_l1"])
+    e_w = max(rel_l2(model.net_g.state_dict()[k].detach().cpu(), v.data) for k, v in params.items())
+    assert e_w < 5e-4, e_w

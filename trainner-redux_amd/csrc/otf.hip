@@ -137,6 +137,35 @@ __global__ __launch_bounds__(256) void warp_bilinear_kernel(const float* __restr
     }
 }
 
+// BT.601 RGB <-> YCbCr on fp32 NCHW 3-channel batches, in the reference's operation order (utils/color_util.py:275-324):
+//   mode 0  rgb2ycbcr_pt:  (rgb . W[:, c] + bias[c]) / 255
+//   mode 1  ycbcr2rgb_pt:  r = 1.164 (y255 - 16) + 1.596 (cr255 - 128) ..., / 255, with y255 = y * 255
+//   mode 2  adjoint of mode 1 (gradient w.r.t. the YCbCr image given the gradient w.r.t. the RGB image; the map is affine with a 255 / 255 = 1 gain)
+__global__ __launch_bounds__(256) void color601_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t hw, int64_t total, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nb = i / hw, p = i - nb * hw;
+        const float* s = src + nb * 3 * hw + p;
+        float* d = dst + nb * 3 * hw + p;
+        const float a = s[0], b = s[hw], c = s[2 * hw];
+        float o0, o1, o2;
+        if (mode == 0) {
+            o0 = ((a * 65.481f + b * 128.553f + c * 24.966f) + 16.f) / 255.f;
+            o1 = ((a * -37.797f + b * -74.203f + c * 112.0f) + 128.f) / 255.f;
+            o2 = ((a * 112.0f + b * -93.786f + c * -18.214f) + 128.f) / 255.f;
+        } else if (mode == 1) {
+            const float y = a * 255.f, cb = b * 255.f, cr = c * 255.f;
+            o0 = (1.164f * (y - 16.f) + 1.596f * (cr - 128.f)) / 255.f;
+            o1 = (1.164f * (y - 16.f) - 0.392f * (cb - 128.f) - 0.813f * (cr - 128.f)) / 255.f;
+            o2 = (1.164f * (y - 16.f) + 2.017f * (cb - 128.f)) / 255.f;
+        } else {
+            o0 = 1.164f * (a + b + c);
+            o1 = -0.392f * b + 2.017f * c;
+            o2 = 1.596f * a - 0.813f * b;
+        }
+        d[0] = o0; d[hw] = o1; d[2 * hw] = o2;
+    }
+}
+
 struct Gain4 { float g[4]; };
 __global__ __launch_bounds__(256) void gain_noise_kernel(const float* __restrict__ src, const float* __restrict__ noise, float* __restrict__ dst, int c, int64_t hw,
                                                           int64_t total, Gain4 gain, float noise_std) {
@@ -206,4 +235,11 @@ extern "C" int tr_warp_bilinear(void* stream, const float* src, float* dst, int 
     hipLaunchKernelGGL(warp_bilinear_kernel, dim3(sweep_grid((int64_t)n * c * h * w)), dim3(256), 0, (hipStream_t)stream, src, dst, n, c, h, w, mode, params_host[0],
                        params_host[1], params_host[2], params_host[3]);
     return tr::launch_status("tr_warp_bilinear");
+}
+
+extern "C" int tr_color601(void* stream, const float* src, float* dst, int n, int64_t hw, int mode) {
+    TR_REQUIRE(src && dst && n > 0 && hw > 0 && mode >= 0 && mode <= 2, TR_EINVAL, "tr_color601: bad arguments (mode 0 rgb->ycbcr, 1 ycbcr->rgb, 2 adjoint of 1)");
+    const int64_t total = (int64_t)n * hw;
+    hipLaunchKernelGGL(color601_kernel, dim3(sweep_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, hw, total, mode);
+    return tr::launch_status("tr_color601");
 }

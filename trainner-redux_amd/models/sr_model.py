@@ -95,6 +95,14 @@ class SRModel:
         self.batch_augment = None
         self.dynamic_loss_scheduler = None
 
+        # input / output pixel formats (sr_model.py:471-481, color_util.py:237-272): "rgb" is the identity; "yuv444" converts LQ to BT.601
+        # YCbCr in front of the generator and its output back to RGB (losses see RGB); the 1- and 2-channel formats ("y", "uv") would need
+        # generators with other channel counts than the HIP ones build
+        fin, fout = getattr(opt, "input_pixel_format", "rgb") or "rgb", getattr(opt, "output_pixel_format", "rgb") or "rgb"
+        for f in (fin, fout):
+            if f not in ("rgb", "yuv444"):
+                raise NotImplementedError(f"pixel format {f!r} is not built on the HIP path (rgb, yuv444)")
+        self._yuv_in, self._yuv_out = fin == "yuv444", fout == "yuv444"
         assert opt.network_g is not None, "network_g must be defined"
         self.net_g = build_network({**opt.network_g, "scale": opt.scale}).to(self.device)
         if hasattr(self.net_g, "compute_dtype"):
@@ -226,6 +234,16 @@ class SRModel:
         if "gt" in data:
             self.gt = self._to_device_f32(data["gt"])
 
+    def _to_input_format(self, img: torch.Tensor) -> torch.Tensor:
+        from .. import ops
+
+        return ops.color601(img, 0) if self._yuv_in else img
+
+    def _to_rgb(self, img: torch.Tensor) -> torch.Tensor:
+        from .. import ops
+
+        return ops.color601(img, 1) if self._yuv_out else img
+
     def _to_device_f32(self, t: torch.Tensor) -> torch.Tensor:
         t = t.to(self.device, non_blocking=True)
         if t.dtype == torch.uint8:
@@ -299,10 +317,14 @@ class SRModel:
             lq, gt = lq.float(), gt.float()
         gt = gt.contiguous()
 
+        lq = self._to_input_format(lq)       # sr_model.py:471: rgb2pixelformat_pt (identity for "rgb")
         if hip_net:
             out = net.train_forward(lq) if hasattr(net, "train_forward") else net.forward_hip(lq, train=True)
+            out = self._to_rgb(out)          # :479-481: pixelformat2rgb_pt
             out_leaf = None
         else:  # foreign generator (stock nn.Module from the open plugin surface): ordinary autograd
+            if self._yuv_in or self._yuv_out:
+                raise NotImplementedError("yuv444 pixel formats are wired for the HIP generators only")
             with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
                 out = net(lq)
         self.output = out.detach()
@@ -382,6 +404,8 @@ class SRModel:
         keys.append("l_g_total")
 
         if hip_net:
+            if self._yuv_out:
+                gout = ops.color601(gout, 2)     # d loss / d(RGB) -> d loss / d(YCbCr network output)
             if hasattr(net, "train_backward"):
                 net.train_backward(gout)
             else:
@@ -536,12 +560,13 @@ class SRModel:
         """sr_model.py:902-945: EMA net if present, whole image or `val.tile_size` tiles."""
         net = self.net_g_ema.ema_model if self.net_g_ema is not None else self.net_g
         assert self.lq is not None
-        lq = self.lq.float()
+        lq = self._to_input_format(self.lq.float())              # sr_model.py:912-914
         val = self.opt.val
         if val is not None and (val.tile_size or 0) > 0:
-            self.output = self.infer_tiled(net, lq)
+            out = self.infer_tiled(net, lq)
         else:
-            self.output = net.forward_hip(lq, train=False) if hasattr(net, "forward_hip") else net(lq)
+            out = net.forward_hip(lq, train=False) if hasattr(net, "forward_hip") else net(lq)
+        self.output = self._to_rgb(out)                          # :936-938
 
     @torch.no_grad()
     def infer_tiled(self, net: nn.Module, lq: Tensor) -> Tensor:

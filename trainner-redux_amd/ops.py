@@ -440,3 +440,13 @@ def adamw_ema(p, g, m, v, ema, *, lr, beta1, beta2, eps, weight_decay, step: int
     d.zero_grad = 1 if zero_grad else 0
     d.inv_scale = inv_scale
     L.check(L.lib().tr_adamw_ema(stream_ptr(), C.byref(d)), "tr_adamw_ema")
+
+
+def color601(src: torch.Tensor, mode: int) -> torch.Tensor:
+    """BT.601 conversion of an fp32 (N, 3, H, W) batch: 0 rgb -> ycbcr, 1 ycbcr -> rgb, 2 adjoint of 1 (utils/color_util.py:275-324)."""
+    _need_cuda(src)
+    src = src.contiguous().float()
+    assert src.dim() == 4 and src.shape[1] == 3, "BT.601 conversions need 3-channel batches"
+    dst = torch.empty_like(src)
+    L.check(L.lib().tr_color601(stream_ptr(), src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[2] * src.shape[3], mode), "tr_color601")
+    return dst
