@@ -169,6 +169,15 @@ class SRModel:
                 self.net_g_ema.ema_model.compute_dtype = self.compute_dtype
         if train_opt.adaptive_d:
             raise NotImplementedError("adaptive_d (sr_model.py:558-569) is not on the HIP path yet")
+        # options that change the step and are not built must not be ignored silently
+        if train_opt.use_moa:
+            raise NotImplementedError("use_moa (batch mixing augmentations, sr_model.py:434-450) is not on the HIP path yet")
+        dls = train_opt.dynamic_loss_scheduling
+        if isinstance(dls, dict) and dls.get("enabled"):
+            raise NotImplementedError("dynamic_loss_scheduling is not on the HIP path yet")
+        ta = train_opt.training_automations
+        if isinstance(ta, dict) and ta.get("enabled"):
+            raise NotImplementedError("training_automations belong to the reference's training loop (train.py), which this package does not replace")
         self.grad_clip = train_opt.grad_clip
         self.grad_clip_threshold = 1.0   # get_automation_clipping_threshold() default without automations
         if train_opt.losses is None:
