@@ -151,6 +151,96 @@ __global__ __launch_bounds__(256) void dwconv_kernel(tr_view in, tr_view out, co
     }
 }
 
+// 16-bit views, LDS-staged: the (TH + K - 1) x (TW + K - 1) halo of the workgroup's 32 channels is loaded ONCE with 16-byte pieces (zeros where
+// the image ends, so the inner loop carries no padding logic) and the K * (TH + K - 1) column reads of every thread come from LDS
+// (ds_read_b64, 512 contiguous bytes per wave).  The direct-from-global version above re-fetched every input value K times through L1 / L2
+// (63 us for 64 channels at 64 x 64 x 64, neither VALU- nor HBM-bound); fp32 views keep it (their halo does not fit two workgroups per CU).
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_lds_kernel(tr_view in, tr_view out, const float* __restrict__ wt, const float* __restrict__ bias, int h, int w, int c,
+                                                          int flip, int nstrips, int ncolblk, int ncb, int vout) {
+    constexpr int P = K / 2;
+    constexpr int NR = DW_TH + K - 1, NC = DW_TW + K - 1;
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    uint2* hl = (uint2*)dsm;                                  // [NR][NC][8] x 4 channels
+    float* wl = (float*)(dsm + NR * NC * 64);                 // [K*K][32]
+    int b = blockIdx.x;
+    const int cb = b % ncb; b /= ncb;
+    const int xb = b % ncolblk; b /= ncolblk;
+    const int sb = b % nstrips;
+    const int nb = b / nstrips;
+    const int y0 = sb * DW_TH, x0 = xb * DW_TW;
+    for (int i = threadIdx.x; i < K * K * DW_CB; i += 256) {
+        const int ch = i % DW_CB, tap = i / DW_CB;
+        const int cc = cb * DW_CB + ch;
+        wl[i] = cc < c ? wt[(int64_t)cc * K * K + (flip ? K * K - 1 - tap : tap)] : 0.f;
+    }
+    {
+        const char* ibase = image_base<true>(in, nb, h, w) + (size_t)cb * DW_CB * 2;
+        const uint32_t rowpitch = (uint32_t)w * in.cstride * 2, colpitch = (uint32_t)in.cstride * 2;
+        constexpr int NPIECE = NR * NC * 4;
+        constexpr int NIT = (NPIECE + 255) / 256;
+        uint4 piece[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pi = threadIdx.x + it * 256;
+            const int pix = pi >> 2, part = pi & 3;
+            const int r = pix / NC, cc = pix - r * NC;
+            const int iy = y0 + r - P, ix = x0 + cc - P;
+            const int ch0 = cb * DW_CB + part * 8;
+            const bool ok = pi < NPIECE && iy >= 0 && iy < h && ix >= 0 && ix < w && ch0 < c;
+            const char* src = ibase + (uint32_t)min(max(iy, 0), h - 1) * rowpitch + (uint32_t)min(max(ix, 0), w - 1) * colpitch + part * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                if (ch0 + 8 <= c) v = *(const uint4*)src;
+                else { const uint2 lo = *(const uint2*)src; v.x = lo.x; v.y = lo.y; }      // a 4-channel tail (c % 8 == 4)
+            }
+            piece[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int pi = threadIdx.x + it * 256;
+            if (pi < NPIECE) ((uint4*)hl)[pi] = piece[it];
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, col = threadIdx.x >> 3;
+    const int c0 = cb * DW_CB + q * 4;
+    const int ox = x0 + col;
+    if (c0 >= c || ox >= w) return;
+    float4 acc[DW_TH];
+    {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) b4 = make_float4(bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]);
+#pragma unroll
+        for (int o = 0; o < DW_TH; ++o) acc[o] = b4;
+    }
+#pragma unroll 1
+    for (int kx = 0; kx < K; ++kx) {
+        float4 wc[K];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) wc[ky] = *(const float4*)&wl[(ky * K + kx) * DW_CB + q * 4];
+        const uint2* colp = hl + (col + kx) * 8 + q;
+        uint2 raw[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) raw[r] = colp[r * NC * 8];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const float4 v = raw_cvt4(raw[r], in.dtype, true);
+#pragma unroll
+            for (int o = 0; o < DW_TH; ++o) {
+                const int ky = r - o;
+                if (ky >= 0 && ky < K) fma4(acc[o], wc[ky], v);
+            }
+        }
+    }
+    const int64_t img = (int64_t)nb * h;
+#pragma unroll
+    for (int o = 0; o < DW_TH; ++o) {
+        const int oy = y0 + o;
+        if (oy < h) tr::view_store4(out, (img + oy) * w + ox, c0, acc[o], vout);
+    }
+}
+
 // Weight gradient: dW[c][ky][kx] = sum_p gy[p][c] * x[p + (ky - P, kx - P)][c].  A thread keeps the DW_TH gradient values of its
 // (column, quad) in registers and, for each kx in turn, walks the K + TH - 1 input rows of the column shifted by kx - P accumulating the K
 // vertical taps (the next kx's column is in flight meanwhile).  After each kx the 8 columns of a wave are summed through a private LDS
@@ -381,8 +471,13 @@ extern "C" int tr_dwconv(void* stream, tr_view in, tr_view out, const float* wei
     hipStream_t st = (hipStream_t)stream;
     const int vin = tr::view_vec4_ok(in), vout = tr::view_vec4_ok(out);
 #define TR_DW(K, H) hipLaunchKernelGGL((dwconv_kernel<K, H>), grid, dim3(256), 0, st, in, out, weight, bias, h, w, c, flip ? 1 : 0, g.nstrips, g.ncolblk, g.ncb, vin, vout)
-    if (in.dtype == TR_F32) { if (ksize == 7) TR_DW(7, false); else if (ksize == 5) TR_DW(5, false); else TR_DW(3, false); }
+    const bool lds_ok = in.dtype != TR_F32 && in.cstride % 8 == 0 && in.coff % 8 == 0 && ((uintptr_t)in.ptr) % 16 == 0;
+#define TR_DWL(K) hipLaunchKernelGGL(dwconv_lds_kernel<K>, grid, dim3(256), (size_t)((DW_TH + K - 1) * (DW_TW + K - 1) * 64 + K * K * DW_CB * 4), st, in, out, weight, \
+                                     bias, h, w, c, flip ? 1 : 0, g.nstrips, g.ncolblk, g.ncb, vout)
+    if (lds_ok) { if (ksize == 7) TR_DWL(7); else if (ksize == 5) TR_DWL(5); else TR_DWL(3); }
+    else if (in.dtype == TR_F32) { if (ksize == 7) TR_DW(7, false); else if (ksize == 5) TR_DW(5, false); else TR_DW(3, false); }
     else { if (ksize == 7) TR_DW(7, true); else if (ksize == 5) TR_DW(5, true); else TR_DW(3, true); }
+#undef TR_DWL
 #undef TR_DW
     return tr::launch_status("tr_dwconv");
 }
