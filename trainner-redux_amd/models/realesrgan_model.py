@@ -9,7 +9,7 @@ Unlike the reference (hard-coded `.cuda()` on a DiffJPEG module it never calls, 
 Overlap.  The compression stage is a host codec round trip (as in the reference), i.e. a device -> host -> device hop in the middle of
 the feed.  On the training stream that hop waits for everything queued before it -- the whole previous step -- and the GPU then idles while
 the host runs the codec and re-fills the launch queue: configs[2] (ESRGAN + VGG + UNet-D, batch 8, 64 -> 256; 52.8 ms of GPU work per
-step) measured 81 ms/step that way.  The feed therefore runs on its own high-priority HIP stream: its kernels and copies interleave with
+step) measured 81 ms/step that way (62 ms/step now, 55 with `use_compile`: side stream + batch-parallel codec + no hidden syncs in the step).  The feed therefore runs on its own high-priority HIP stream: its kernels and copies interleave with
 the previous step still executing on the training stream, the host waits only for that stream's few small kernels, and the training stream
 just waits on an event before it reads the new pair.  `prefetch(data)` additionally splits the feed so that the device half of the NEXT batch
 is issued before the current step (the codec then finds its pixels already in pinned memory).  Same thread, same RNG draw order.
