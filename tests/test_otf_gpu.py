@@ -223,3 +223,38 @@ def test_resize_pt_matches_the_reference_function(cuda):
             assert out.shape == ref.shape, (tag, mode)
             err = (out - ref).abs().max().item()
             assert err < (1e-7 if mode == "nearest-exact" else 3e-6), (tag, mode, err)
+
+
+def test_otf_feed_end_to_end_from_image_files(cuda, tmp_path):
+    """Files on disk -> RealESRGANDataset (GT tile + three kernels per sample) -> DataLoader -> DevicePrefetcher (pinned H2D on a side
+    stream) -> RealESRGANModel.feed_data (device degradations, codec hop, crop, pool) -> optimize_parameters: the whole OTF feed path."""
+    import random
+
+    import numpy as np
+    from PIL import Image
+
+    from trainner_redux_amd.data import DevicePrefetcher, EnlargedSampler, RealESRGANDataset, build_dataloader
+    from trainner_redux_amd.models import build_model
+
+    g = np.random.default_rng(1)
+    for i in range(6):
+        Image.fromarray(g.integers(0, 255, (150 + 7 * i, 170, 3), dtype=np.uint8)).save(tmp_path / f"{i}.png")
+    opt = _otf_opt(compression_formats=["jpeg", "webp"], compression_weights=[0.5, 0.5], blur_prob=1.0, sensor_noise_prob=0.5, exposure_prob=0.5,
+                   datasets=dict(train=dict(name="x", type="realesrgandataset", dataroot_gt=[str(tmp_path)], lq_size=16, gt_size=64, batch_size_per_gpu=2,
+                                            sinc_prob=0.3, final_sinc_prob=0.5)))
+    random.seed(3)
+    ds = RealESRGANDataset(opt.datasets["train"], rng=np.random.default_rng(3))
+    loader = build_dataloader(ds, batch_size=2, sampler=EnlargedSampler(ds, 1, 0, ratio=2))
+    feed = DevicePrefetcher(loader, cuda)
+    model = build_model(opt)
+    steps = 0
+    while True:
+        batch = feed.next()
+        if batch is None:
+            break
+        assert batch["gt"].is_cuda and batch["gt"].shape == (2, 3, 96, 96) and batch["kernel1"].shape == (2, 21, 21)
+        model.feed_data(batch)
+        assert model.lq.shape == (2, 3, 16, 16) and model.gt.shape == (2, 3, 64, 64)
+        steps += 1
+        model.optimize_parameters(steps, 0, True)
+    assert steps == 6 and model.get_current_log()["l_g_l1"] > 0
