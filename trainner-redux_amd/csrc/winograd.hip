@@ -36,7 +36,10 @@ constexpr int U_FLOATS = 16 * 2 * W_KB * 4;   // 8192 floats = 32 KB per (group,
 constexpr int V_FLOATS = 16 * 2 * W_TB * 4;   // 8192 floats = 32 KB
 constexpr int STAGE_FLOATS = U_FLOATS + V_FLOATS;
 constexpr int T_STRIDE = 36;                  // floats per (j, r, tile) row of the exchange buffer (32 + 4: b128-aligned, conflict free)
-constexpr int SMEM_BYTES = 2 * STAGE_FLOATS * 4;        // 128 KB (the exchange buffer, 4*2*64*36*4 = 73,728 B, reuses it)
+constexpr int HALO = 18;                      // 8 x 8 tiles of 2 x 2 outputs + the 3 x 3 window: 18 x 18 input pixels per workgroup
+constexpr int RAW_STRIDE = 12;                // floats per halo pixel in LDS (8 channels + 4: 16-byte aligned rows, 2-way instead of 4-way read conflicts)
+constexpr int RAW_FLOATS = HALO * HALO * RAW_STRIDE;    // 3888 floats = 15.2 KB per buffer
+constexpr int SMEM_BYTES = (2 * STAGE_FLOATS + 2 * RAW_FLOATS) * 4;      // 128 KB + 30.4 KB (the exchange buffer, 73,728 B, reuses the stages)
 
 struct WinoArgs {
     int n, h, w, cin, cout;
@@ -63,44 +66,50 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
     // ---- loader role: channel lc of the chunk, tile lt of the workgroup ---------------------------------------------------------------
     const int lc = tid & 7, lt = tid >> 3;
     const int py0 = 2 * (by * 8 + (lt >> 3)) - 1, px0 = 2 * (bx * 8 + (lt & 7)) - 1;     // top-left pixel of the 4 x 4 input patch (pad 1)
-    // Branch-free patch loads: every load goes out unconditionally from a clamped address and padding is a select afterwards.  (Guarding
-    // each load with its own condition made the compiler put it in its own basic block: 183 branches in the kernel, loads serialised
-    // behind waits, and no overlap at all between the loader work and the MFMAs.)
-    unsigned okmask = 0;
-    int yo[4], xo[4];
+    // The 18 x 18 x 8-channel halo of a chunk is fetched ONCE per workgroup with 16-byte loads (648 pieces: one or two per thread, zero
+    // padding applied on the way into LDS) and every thread then picks the 16 values of its (tile, channel) patch out of LDS.  Fetching
+    // the patches directly cost 16 scalar loads per thread and chunk -- 3.2x redundant between neighbouring tiles -- and kept the CU's
+    // texture-address unit busier than its MFMA pipes (8 waves x 20 vector-memory instructions per chunk of 32 MFMAs each).
+    float* rawb = stage + 2 * STAGE_FLOATS;
+    const float* inimg = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff;
+    int roff[2], rdst[2];
+    bool rok[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = py0 + r, x = px0 + r;
-        if (y >= 0 && y < a.h) okmask |= 0xFu << (4 * r);
-        yo[r] = min(max(y, 0), a.h - 1) * (a.w * a.in.cstride);
-        xo[r] = min(max(x, 0), a.w - 1) * a.in.cstride;
+    for (int j = 0; j < 2; ++j) {
+        const int piece = tid + j * W_THREADS;
+        const int pix = min(piece, HALO * HALO * 2 - 1) >> 1, half = piece & 1;
+        const int hy = pix / HALO, hx = pix - hy * HALO;
+        const int y = by * 16 - 1 + hy, x = bx * 16 - 1 + hx;
+        rok[j] = y >= 0 && y < a.h && x >= 0 && x < a.w;
+        roff[j] = (min(max(y, 0), a.h - 1) * a.w + min(max(x, 0), a.w - 1)) * a.in.cstride + half * 4;
+        rdst[j] = pix * RAW_STRIDE + half * 4;
     }
-    {
-        unsigned cm = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (px0 + c >= 0 && px0 + c < a.w) cm |= 0x1111u << c;
-        okmask &= cm;
-    }
-    const float* inb = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff + lc;
+    const bool second = tid < HALO * HALO * 2 - W_THREADS;       // threads that carry a second piece
     const f32x4* ub = (const f32x4*)(a.u + (int64_t)kg * a.nchunks * U_FLOATS) + tid;
-    float d[16];
+    f32x4 rawreg[2];
     f32x4 ureg[4];
-    auto issue = [&](int ch) {                   // ch may run past the last chunk (clamped: a redundant load instead of a branch)
-        const int chc = min(ch, a.nchunks - 1);
-        const float* src = inb + chc * W_CK;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) d[p] = src[yo[p >> 2] + xo[p & 3]];
-        const f32x4* us = ub + (int64_t)chc * (U_FLOATS / 4);
+    auto issue_in = [&](int ch) {                // ch may run past the last chunk (clamped: a redundant load instead of a branch)
+        const float* src = inimg + min(ch, a.nchunks - 1) * W_CK;
+        rawreg[0] = *(const f32x4*)(src + roff[0]);
+        rawreg[1] = *(const f32x4*)(src + roff[1]);
+    };
+    auto issue_u = [&](int ch) {
+        const f32x4* us = ub + (int64_t)min(ch, a.nchunks - 1) * (U_FLOATS / 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) ureg[j] = us[j * W_THREADS];
     };
+    auto put_raw = [&](float* rb) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(rb + rdst[0]) = rok[0] ? rawreg[0] : z;
+        if (second) *(f32x4*)(rb + rdst[1]) = rok[1] ? rawreg[1] : z;
+    };
+    const int rsrc = (((lt >> 3) * 2) * HALO + (lt & 7) * 2) * RAW_STRIDE + lc;          // top-left value of this thread's patch in a raw buffer
     const int voff = U_FLOATS + ((lc & 1) * W_TB + lt) * 4 + (lc >> 1);                  // + xi * 512 floats within a stage
-    auto fill = [&](float* st) {                 // registers of the prefetched chunk -> one LDS stage
+    auto fill = [&](float* st, const float* rb) {    // raw halo + weight registers of a chunk -> one LDS stage
         // V = B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        float t[16];
+        float t[16], d[16];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) d[p] = ((okmask >> p) & 1u) ? d[p] : 0.f;       // zero padding
+        for (int p = 0; p < 16; ++p) d[p] = rb[rsrc + ((p >> 2) * HALO + (p & 3)) * RAW_STRIDE];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             t[0 + x] = d[0 + x] - d[8 + x];
@@ -154,19 +163,70 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
         }
     };
 
-    issue(0);
-    fill(stage);
-    issue(1);
+    issue_in(0);
+    issue_u(0);
+    put_raw(rawb);
+    issue_in(1);
+    __syncthreads();
+    fill(stage, rawb);
+    put_raw(rawb + RAW_FLOATS);
+    issue_in(2);
+    issue_u(1);
     __syncthreads();
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const float* ul = stage + (ch & 1) * STAGE_FLOATS;
-        // straight-line body: the fill after the last chunk writes a stage nobody reads, the loads past the end re-read the last chunk
-        fill(stage + ((ch + 1) & 1) * STAGE_FLOATS);       // the other stage was released by the barrier that ended the previous iteration
-        issue(ch + 2);                                     // two chunks ahead of the MFMAs below
-        mfmas(ul, ul + U_FLOATS);
-        // barrier on the LDS traffic only (__syncthreads() would also drain the global loads just issued for chunk ch + 2)
+        float* nst = stage + ((ch + 1) & 1) * STAGE_FLOATS;
+        const float* rb = rawb + ((ch + 1) & 1) * RAW_FLOATS;
+        // Three chunks in flight: MFMAs on chunk ch; stage fill for ch + 1 (from the raw halo written one iteration ago) tucked behind the
+        // first two MFMA steps of this wave; raw halo of ch + 2 into LDS and the loads of ch + 3 behind the second step.
+        float d[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) d[p] = rb[rsrc + ((p >> 2) * HALO + (p & 3)) * RAW_STRIDE];     // lands during the first MFMA step
+        const float* ua = ul + (lh * W_KB + lr) * 4;
+        const float* vb = ul + U_FLOATS + (lh * W_TB + wth * 32 + lr) * 4;
+        f32x4 bv[2], au[2][2];
+        bv[0] = *(const f32x4*)(vb + wj * 512);
+        au[0][0] = *(const f32x4*)(ua + wj * 512);
+        au[0][1] = *(const f32x4*)(ua + wj * 512 + 128);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i + 1 < 4) {
+                const int xi2 = (i + 1) * 4 + wj;
+                bv[(i + 1) & 1] = *(const f32x4*)(vb + xi2 * 512);
+                au[(i + 1) & 1][0] = *(const f32x4*)(ua + xi2 * 512);
+                au[(i + 1) & 1][1] = *(const f32x4*)(ua + xi2 * 512 + 128);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[i & 1][0][e], bv[i & 1][e], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(au[i & 1][1][e], bv[i & 1][e], acc[i][1], 0, 0, 0);
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {                // B^T d in place
+                    const float a0 = d[0 + x], a1 = d[4 + x], a2 = d[8 + x], a3 = d[12 + x];
+                    d[0 + x] = a0 - a2; d[4 + x] = a1 + a2; d[8 + x] = a2 - a1; d[12 + x] = a1 - a3;
+                }
+            }
+            {   // one quarter of the next stage's fill behind every MFMA step: V row i and the i-th 16-byte piece of U; that piece's register
+                // is re-loaded for chunk ch + 2 at once (rolling prefetch: a whole chunk of lead, no second register set)
+                float* vdst = nst + voff;
+                vdst[(i * 4 + 0) * 512] = d[i * 4 + 0] - d[i * 4 + 2];
+                vdst[(i * 4 + 1) * 512] = d[i * 4 + 1] + d[i * 4 + 2];
+                vdst[(i * 4 + 2) * 512] = d[i * 4 + 2] - d[i * 4 + 1];
+                vdst[(i * 4 + 3) * 512] = d[i * 4 + 1] - d[i * 4 + 3];
+                ((f32x4*)nst)[tid + i * W_THREADS] = ureg[i];
+                ureg[i] = (ub + (int64_t)min(ch + 2, a.nchunks - 1) * (U_FLOATS / 4))[i * W_THREADS];
+            }
+            if (i == 2) {
+                put_raw(rawb + (ch & 1) * RAW_FLOATS);     // chunk ch + 2; this buffer's previous content (chunk ch) was consumed an iteration ago
+                issue_in(ch + 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // this stage consumed by every wave, the other stage completely written
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- output transform + epilogue, one 32-channel half at a time ------------------------------------------------------------------------
@@ -216,6 +276,200 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
     }
 }
 
+// ---- second formulation: 16x16x4 MFMAs, one wave = all 16 positions of a 16-channel x 32-tile block --------------------------------------
+// Workgroup = 256 threads = 4 waves = 64 output channels x 32 tiles (4 x 8 tiles, 8 x 16 output pixels); two to three workgroups per CU.
+// Differences from the kernel above, each aimed at what its counters showed (MFMA pipe idle 35 %: every wave fills LDS at the same time,
+// and most of that fill is LDS WRITE time -- ds_write_b32 moves 64 B/clk, ds_write_b128 79 B/clk):
+//   * the weights never touch LDS: a wave's A fragments (its own 16 channels, 8 input channels, 16 positions: 32 VGPRs) come straight from
+//     the packed array with 8-byte loads that are contiguous over the wave, and each position's registers are re-loaded for the NEXT chunk
+//     right after their last MFMA of this chunk (a rolling prefetch with almost a whole chunk of lead and no second register set);
+//   * only V goes through LDS: 16 KB per chunk and workgroup instead of 64 KB;
+//   * a lane holds all 16 positions of its (channel quad, tile) elements, so the output transform A^T M A is pure register arithmetic:
+//     no exchange through LDS, no epilogue barriers, 16-byte stores;
+//   * the two waves that share a SIMD belong to different workgroups and drift apart by themselves.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+constexpr int B_TB = 32, B_KB = 64, B_THREADS = 256;
+constexpr int BV_FLOATS = 16 * 256;            // V of one chunk: [xi][tile block 2][kq 4][tile 16][step 2] = 16 KB
+constexpr int BU_FLOATS = 4 * 16 * 64 * 2;      // packed U of one (group, chunk): [wave 4][xi 16][lane 64][step 2] = 32 KB
+
+__global__ __launch_bounds__(B_THREADS, 2) void winograd16_f32_kernel(WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float vstage[2][BV_FLOATS];
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wv = tid >> 6;
+    int b = blockIdx.x;
+    const int kg = b % a.nkg; b /= a.nkg;
+    const int bx = b % a.ntx; b /= a.ntx;
+    const int by = b % a.nty;
+    const int nb = b / a.nty;
+    // ---- loader role -------------------------------------------------------------------------------------------------------------------
+    const int lc = tid & 7, lt = tid >> 3;
+    const int py0 = 2 * (by * 4 + (lt >> 3)) - 1, px0 = 2 * (bx * 8 + (lt & 7)) - 1;
+    unsigned okmask = 0;
+    int yo[4], xo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = py0 + r, x = px0 + r;
+        if (y >= 0 && y < a.h) okmask |= 0xFu << (4 * r);
+        yo[r] = min(max(y, 0), a.h - 1) * (a.w * a.in.cstride);
+        xo[r] = min(max(x, 0), a.w - 1) * a.in.cstride;
+    }
+    {
+        unsigned cm = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (px0 + c >= 0 && px0 + c < a.w) cm |= 0x1111u << c;
+        okmask &= cm;
+    }
+    const float* inb = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff + lc;
+    float d[16];
+    auto issue = [&](int ch) {
+        const float* src = inb + min(ch, a.nchunks - 1) * W_CK;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) d[p] = src[yo[p >> 2] + xo[p & 3]];
+    };
+    // V element of (tile lt, channel lc): [xi][tb = lt >> 4][kq = lc & 3][j = lt & 15][step = lc >> 2]
+    const int voff = (((lt >> 4) * 4 + (lc & 3)) * 16 + (lt & 15)) * 2 + (lc >> 2);
+    auto fill = [&](float* st) {
+        float t[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) d[p] = ((okmask >> p) & 1u) ? d[p] : 0.f;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            t[0 + x] = d[0 + x] - d[8 + x];
+            t[4 + x] = d[4 + x] + d[8 + x];
+            t[8 + x] = d[8 + x] - d[4 + x];
+            t[12 + x] = d[4 + x] - d[12 + x];
+        }
+        float* vdst = st + voff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vdst[(i * 4 + 0) * 256] = t[i * 4 + 0] - t[i * 4 + 2];
+            vdst[(i * 4 + 1) * 256] = t[i * 4 + 1] + t[i * 4 + 2];
+            vdst[(i * 4 + 2) * 256] = t[i * 4 + 2] - t[i * 4 + 1];
+            vdst[(i * 4 + 3) * 256] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+    };
+    // ---- MFMA role -----------------------------------------------------------------------------------------------------------------------
+    const f32x2* ubase = (const f32x2*)(a.u + ((int64_t)kg * a.nchunks * 4 + wv) * (16 * 64 * 2)) + l;     // + (ch * 4 * 16 + xi) * 64
+    auto loadA = [&](int ch, int xi) { return ubase[((int64_t)min(ch, a.nchunks - 1) * 64 + xi) * 64]; };
+    f32x2 af[16];
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        af[xi] = loadA(0, xi);
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[xi][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    issue(0);
+    fill(vstage[0]);
+    issue(1);
+    __syncthreads();
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const float* vl = vstage[ch & 1] + l * 2;            // lane (kq = l >> 4, j = l & 15): ((tb * 4 + kq) * 16 + j) * 2 = tb * 128 + l * 2
+        fill(vstage[(ch + 1) & 1]);
+        issue(ch + 2);
+        f32x2 bq[2][2];
+        bq[0][0] = *(const f32x2*)(vl);
+        bq[0][1] = *(const f32x2*)(vl + 128);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            if (xi + 1 < 16) {
+                bq[(xi + 1) & 1][0] = *(const f32x2*)(vl + (xi + 1) * 256);
+                bq[(xi + 1) & 1][1] = *(const f32x2*)(vl + (xi + 1) * 256 + 128);
+            }
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[xi][st], bq[xi & 1][0][st], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[xi][st], bq[xi & 1][1][st], acc[xi][1], 0, 0, 0);
+            }
+            af[xi] = loadA(ch + 1, xi);                       // rolling prefetch: this position's registers are free until the next chunk
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // ---- output transform in registers + epilogue ------------------------------------------------------------------------------------------
+    const int kq4 = (l >> 4) * 4;                            // the lane's 4 consecutive channels: D[i = 4 (l / 16) + r][j = l % 16]
+    const int kc = kg * B_KB + wv * 16 + kq4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = a.bias[kc + r];
+    }
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int t = tb * 16 + (l & 15);
+        const int ty = by * 4 + (t >> 3), tx = bx * 8 + (t & 7);
+        float y[2][2][4];                                     // [row][col][channel]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float T[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m0 = acc[0 + j][tb][r], m1 = acc[4 + j][tb][r], m2 = acc[8 + j][tb][r], m3 = acc[12 + j][tb][r];
+                T[j][0] = m0 + m1 + m2;
+                T[j][1] = m1 - m2 - m3;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                y[rr][0][r] = T[0][rr] + T[1][rr] + T[2][rr];
+                y[rr][1][r] = T[1][rr] - T[2][rr] - T[3][rr];
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int oy = 2 * ty + rr;
+            if (oy >= a.h) continue;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ox = 2 * tx + s;
+                if (ox >= a.w) continue;
+                const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = y[rr][s][r] + bias4[r];
+                    if (a.act == TR_ACT_RELU) e = fmaxf(e, 0.f);
+                    v[r] = e;
+                }
+                if (a.mask.ptr) {
+                    const f32x4 m = *(const f32x4*)((const float*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + kc);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= m[r] > 0.f ? 1.f : a.mask_slope;
+                }
+                *(f32x4*)((float*)a.out.ptr + pix * a.out.cstride + a.out.coff + kc) = v;
+            }
+        }
+    }
+}
+
+// packed U for the kernel above: [co / 64][ci / 8][wave = (co % 64) / 16][xi][lane = ((ci % 8) & 3) * 16 + co % 16][step = (ci % 8) >> 2]
+__global__ __launch_bounds__(256) void winograd16_pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin, int src_i, int transpose) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)cout * cin) return;
+    const int co = (int)(i / cin), ci = (int)(i % cin);
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = transpose ? w[((int64_t)ci * src_i + co) * 9 + (8 - t)] : w[((int64_t)co * src_i + ci) * 9 + t];
+    float gg[12];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        gg[0 + x] = g[0 + x];
+        gg[3 + x] = 0.5f * (g[0 + x] + g[3 + x] + g[6 + x]);
+        gg[6 + x] = 0.5f * (g[0 + x] - g[3 + x] + g[6 + x]);
+        gg[9 + x] = g[6 + x];
+    }
+    const int nchunks = cin / W_CK, cc = ci % W_CK;
+    float* base = dst + (((int64_t)(co / 64) * nchunks + ci / W_CK) * 4 + (co % 64) / 16) * (16 * 64 * 2) + ((cc & 3) * 16 + co % 16) * 2 + (cc >> 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a0 = gg[r * 3 + 0], a1 = gg[r * 3 + 1], a2 = gg[r * 3 + 2];
+        base[(r * 4 + 0) * 128] = a0;
+        base[(r * 4 + 1) * 128] = 0.5f * (a0 + a1 + a2);
+        base[(r * 4 + 2) * 128] = 0.5f * (a0 - a1 + a2);
+        base[(r * 4 + 3) * 128] = a2;
+    }
+}
+
 // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], for g = w[co][ci] (or, transposed, the input-gradient kernel w[ci][co] with its taps
 // mirrored); written in the LDS image order of the kernel above: [co / 64][ci / 8][xi][kk = ci & 1][co % 64][s = (ci % 8) >> 1].
 __global__ __launch_bounds__(256) void winograd_pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin, int src_o, int src_i,
@@ -247,6 +501,11 @@ __global__ __launch_bounds__(256) void winograd_pack_kernel(const float* __restr
     }
 }
 
+inline bool wino_impl16() {      // TRAINNER_WINO_IMPL=16: the 16x16x4 formulation (pack and conv must agree: read once per process)
+    static const bool v = getenv("TRAINNER_WINO_IMPL") && atoi(getenv("TRAINNER_WINO_IMPL")) == 16;
+    return v;
+}
+
 inline bool wino_view_ok(const tr_view& v, int c) { return v.ptr && v.dtype == TR_F32 && v.c >= c && v.coff >= 0 && v.coff + c <= v.cstride; }
 
 }  // namespace
@@ -258,6 +517,11 @@ extern "C" int tr_pack_winograd(void* stream, const float* w_oihw, float* dst, i
                "tr_pack_winograd: cout=%d must be a multiple of %d and cin=%d of %d", cout, W_KB, cin, W_CK);
     TR_REQUIRE(((uintptr_t)dst) % 16 == 0, TR_EALIGN, "tr_pack_winograd: dst must be 16-byte aligned");
     const int64_t n = (int64_t)cout * cin;
+    if (wino_impl16()) {
+        hipLaunchKernelGGL(winograd16_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, dst, cout, cin,
+                           transpose ? cout : cin, transpose ? 1 : 0);
+        return tr::launch_status("tr_pack_winograd");
+    }
     // the OIHW source is cout x cin (direct) or cin x cout (transpose: the conv being differentiated maps cout-many inputs ... see header)
     hipLaunchKernelGGL(winograd_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, dst, cout, cin,
                        transpose ? cin : cout, transpose ? cout : cin, transpose ? 1 : 0);
@@ -278,6 +542,8 @@ extern "C" int tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d) {
     TR_REQUIRE(wino_view_ok(d->in, d->cin) && wino_view_ok(d->out, d->cout) && (!d->mask.ptr || wino_view_ok(d->mask, d->cout)) && d->wpacked, TR_EINVAL,
                "tr_conv3x3_winograd_f32: fp32 views holding cin / cout channels and packed weights are required");
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3_winograd_f32: wpacked must be 16-byte aligned");
+    TR_REQUIRE(wino_impl16() || (d->in.cstride % 4 == 0 && d->in.coff % 4 == 0 && ((uintptr_t)d->in.ptr) % 16 == 0), TR_EALIGN,
+               "tr_conv3x3_winograd_f32: the input view must allow aligned 4-channel access");
     TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: one image of the input must stay below 2^31 elements");
     WinoArgs a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
@@ -286,6 +552,16 @@ extern "C" int tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d) {
     a.u = (const float*)d->wpacked; a.bias = d->bias;
     a.nty = (d->h / 2 + 7) / 8; a.ntx = (d->w / 2 + 7) / 8;
     a.nchunks = d->cin / W_CK; a.nkg = d->cout / W_KB;
+    if (wino_impl16()) {
+        TR_REQUIRE(d->out.cstride % 4 == 0 && d->out.coff % 4 == 0 && ((uintptr_t)d->out.ptr) % 16 == 0 &&
+                       (!d->mask.ptr || (d->mask.cstride % 4 == 0 && d->mask.coff % 4 == 0 && ((uintptr_t)d->mask.ptr) % 16 == 0)),
+                   TR_EALIGN, "tr_conv3x3_winograd_f32: output / mask views must allow aligned 4-channel access");
+        a.nty = (d->h / 2 + 3) / 4;
+        const int64_t nb16 = (int64_t)d->n * a.nty * a.ntx * a.nkg;
+        TR_REQUIRE(nb16 < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: grid too large");
+        hipLaunchKernelGGL(winograd16_f32_kernel, dim3((unsigned)nb16), dim3(B_THREADS), 0, (hipStream_t)stream, a);
+        return tr::launch_status("tr_conv3x3_winograd_f32");
+    }
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: grid too large");
     static const hipError_t attr = hipFuncSetAttribute((const void*)winograd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
