@@ -229,12 +229,13 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- output transform + epilogue, one 32-channel half at a time ------------------------------------------------------------------------
+    // ---- output transform + epilogue ------------------------------------------------------------------------------------------------------------
+    // One exchange round for both 32-channel halves ([kh][j][r][tile][36 floats] = 144 KB: the stages and raw buffers are free by now), then
+    // every thread finishes one tile x 4 consecutive channels per half with 16-byte LDS reads and 16-byte stores (8 lanes = the 128
+    // contiguous bytes of a pixel's 32 channels).
     float* tl = (float*)smem;
-    const int ek = tid & 31, etg = tid >> 5;
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh) {
-        if (kh) __syncthreads();                           // the previous half's exchange has been read
+    for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 t0, t1;
@@ -244,33 +245,41 @@ __global__ __launch_bounds__(W_THREADS, 1) void winograd_f32_kernel(WinoArgs a) 
                 t0[e] = m0 + m1 + m2;                      // A^T = [1 1 1 0; 0 1 -1 -1] applied down column j
                 t1[e] = m1 - m2 - m3;
             }
-            *(f32x4*)(tl + ((wj * 2 + 0) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t0;
-            *(f32x4*)(tl + ((wj * 2 + 1) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t1;
+            *(f32x4*)(tl + (((kh * 4 + wj) * 2 + 0) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t0;
+            *(f32x4*)(tl + (((kh * 4 + wj) * 2 + 1) * W_TB + wth * 32 + lr) * T_STRIDE + q * 8 + lh * 4) = t1;
         }
-        __syncthreads();
-        const int kc = kg * W_KB + kh * 32 + ek;
-        const float bias = a.bias ? a.bias[kc] : 0.f;
+    __syncthreads();
+    const int ek4 = (tid & 7) * 4, et = tid >> 3;
+    const int ty = by * 8 + (et >> 3), tx = bx * 8 + (et & 7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int t = etg + 16 * i;
-            const int ty = by * 8 + (t >> 3), tx = bx * 8 + (t & 7);
+    for (int kh = 0; kh < 2; ++kh) {
+        const int kc = kg * W_KB + kh * 32 + ek4;
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bias = *(const f32x4*)(a.bias + kc);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const float T0 = tl[((0 * 2 + r) * W_TB + t) * T_STRIDE + ek], T1 = tl[((1 * 2 + r) * W_TB + t) * T_STRIDE + ek];
-                const float T2 = tl[((2 * 2 + r) * W_TB + t) * T_STRIDE + ek], T3 = tl[((3 * 2 + r) * W_TB + t) * T_STRIDE + ek];
-                const float y[2] = {T0 + T1 + T2, T1 - T2 - T3};
-                const int oy = 2 * ty + r;
-                if (oy >= a.h) continue;
+        for (int r = 0; r < 2; ++r) {
+            const float* tp = tl + ((kh * 4 * 2 + r) * W_TB + et) * T_STRIDE + ek4;
+            const f32x4 T0 = *(const f32x4*)(tp), T1 = *(const f32x4*)(tp + 2 * W_TB * T_STRIDE);
+            const f32x4 T2 = *(const f32x4*)(tp + 4 * W_TB * T_STRIDE), T3 = *(const f32x4*)(tp + 6 * W_TB * T_STRIDE);
+            const f32x4 y[2] = {T0 + T1 + T2, T1 - T2 - T3};
+            const int oy = 2 * ty + r;
+            if (oy >= a.h) continue;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int ox = 2 * tx + s;
-                    if (ox >= a.w) continue;
-                    const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
-                    float v = y[s] + bias;
-                    if (a.act == TR_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (a.mask.ptr) v *= ((const float*)a.mask.ptr)[pix * a.mask.cstride + a.mask.coff + kc] > 0.f ? 1.f : a.mask_slope;
-                    ((float*)a.out.ptr)[pix * a.out.cstride + a.out.coff + kc] = v;
+            for (int s = 0; s < 2; ++s) {
+                const int ox = 2 * tx + s;
+                if (ox >= a.w) continue;
+                const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
+                f32x4 v = y[s] + bias;
+                if (a.act == TR_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
+                if (a.mask.ptr) {
+                    const f32x4 m = *(const f32x4*)((const float*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + kc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= m[e] > 0.f ? 1.f : a.mask_slope;
+                }
+                *(f32x4*)((float*)a.out.ptr + pix * a.out.cstride + a.out.coff + kc) = v;
             }
         }
     }
@@ -552,10 +561,11 @@ extern "C" int tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d) {
     a.u = (const float*)d->wpacked; a.bias = d->bias;
     a.nty = (d->h / 2 + 7) / 8; a.ntx = (d->w / 2 + 7) / 8;
     a.nchunks = d->cin / W_CK; a.nkg = d->cout / W_KB;
+    TR_REQUIRE(d->out.cstride % 4 == 0 && d->out.coff % 4 == 0 && ((uintptr_t)d->out.ptr) % 16 == 0 &&
+                   (!d->mask.ptr || (d->mask.cstride % 4 == 0 && d->mask.coff % 4 == 0 && ((uintptr_t)d->mask.ptr) % 16 == 0)) &&
+                   (!d->bias || ((uintptr_t)d->bias) % 16 == 0),
+               TR_EALIGN, "tr_conv3x3_winograd_f32: output / mask views and the bias must allow aligned 4-channel access");
     if (wino_impl16()) {
-        TR_REQUIRE(d->out.cstride % 4 == 0 && d->out.coff % 4 == 0 && ((uintptr_t)d->out.ptr) % 16 == 0 &&
-                       (!d->mask.ptr || (d->mask.cstride % 4 == 0 && d->mask.coff % 4 == 0 && ((uintptr_t)d->mask.ptr) % 16 == 0)),
-                   TR_EALIGN, "tr_conv3x3_winograd_f32: output / mask views must allow aligned 4-channel access");
         a.nty = (d->h / 2 + 3) / 4;
         const int64_t nb16 = (int64_t)d->n * a.nty * a.ntx * a.nkg;
         TR_REQUIRE(nb16 < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd_f32: grid too large");
