@@ -403,6 +403,11 @@ int tr_axpby_clamp01(void* stream, const float* a, float wa, const float* b, flo
  *   mode 2 chromatic aberration (realesrgan_model.py:244-311; params[ch] = affine scale of channel ch, 1 = untouched; zero padding, clamp to [0, 1]). */
 int tr_warp_bilinear(void* stream, const float* src, float* dst, int n, int c, int h, int w, int mode, const float* params_host);
 
+/* tr_bayer_round_trip: the demosaicing-artifact stage (realesrgan_model.py:312-363 / paragon_otf_degradations.py:526-556) of an fp32 (N, 3, H, W)
+ * batch: 8-bit quantisation, the reference's one-colour-per-site mosaic, bilinear reconstruction as cv2.demosaicing(COLOR_BAYER_BG2BGR) does it
+ * (OpenCV is a third-party dependency absent here: restated from its published algorithm, parity unpinned), / 255. */
+int tr_bayer_round_trip(void* stream, const float* src, float* dst, int n, int h, int w);
+
 /* ---- input / output pixel formats (sr_model.py:471-481, utils/color_util.py:237-324): BT.601 conversions of fp32 NCHW 3-channel batches.
  * mode 0 = rgb2ycbcr_pt, 1 = ycbcr2rgb_pt, 2 = adjoint of 1 (gradient of the loss w.r.t. a YCbCr network output given d/d(RGB)). */
 int tr_color601(void* stream, const float* src, float* dst, int n, int64_t hw, int mode);

@@ -5,6 +5,7 @@ Follows, function by function,
   filter2d                                             /root/reference/traiNNer/utils/img_process_util.py:8-32   (pinned: tests/golden/filter2d.pt)
   motion blur / exposure / colour temperature / sensor noise        /root/reference/traiNNer/models/paragon_otf_degradations.py:251-294,345-414
   oversharpening, aliasing                             /root/reference/traiNNer/models/realesrgan_model.py:193-241,365-402
+  demosaicing artifacts                                /root/reference/traiNNer/models/realesrgan_model.py:312-363 (cv2.demosaicing restated: unpinned)
   the stage order and RNG draws of feed_data           /root/reference/traiNNer/models/realesrgan_model.py:456-664
 The reference modules themselves do not import here (cv2 / torchvision / msgspec are absent), and RealESRGANModel has no CPU path at all
 (hard-coded .cuda()): resizes are pinned on torch's own F.interpolate, which is what the reference calls; the
@@ -14,6 +15,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 from torch.nn import functional as F
 
@@ -154,3 +156,48 @@ def chromatic_aberration(img):
             x = F.grid_sample(x, F.affine_grid(theta, x.size(), align_corners=False), align_corners=False, mode="bilinear")
         out.append(x)
     return torch.clamp(torch.cat(out, dim=1), 0, 1)
+
+
+def demosaic_artifacts(img):
+    """realesrgan_model.py:327-361 for an (N, 3, H, W) float batch: 8-bit quantisation, the reference's mosaic (channel 2 at even/even sites,
+    channel 0 at odd/odd, channel 1 elsewhere) and cv2.demosaicing(bayer, COLOR_BAYER_BG2BGR).  OpenCV (opencv-python, unpinned in the reference's
+    pyproject) is absent here, so its bilinear demosaicing is restated from the published algorithm (imgproc/demosaicing.cpp, Bayer2RGB_):
+    interior pixels average the 2 or 4 nearest same-colour sites in integers with round-half-up, the first / last columns copy their inner
+    neighbour and then the first / last rows copy theirs.  PARITY UNPINNED for this function: no cv2 output is available to check it against."""
+    x = img.detach().cpu().float().numpy()
+    n, c, h, w = x.shape
+    assert c == 3 and h >= 3 and w >= 3
+    q = (np.clip(x, 0, 1) * np.float32(255)).astype(np.uint8)
+    out = np.zeros((n, 3, h, w), np.uint8)
+    for b in range(n):
+        m = np.zeros((h, w), np.int32)
+        m[0::2, 0::2] = q[b, 2, 0::2, 0::2]
+        m[0::2, 1::2] = q[b, 1, 0::2, 1::2]
+        m[1::2, 0::2] = q[b, 1, 1::2, 0::2]
+        m[1::2, 1::2] = q[b, 0, 1::2, 1::2]
+        o = np.zeros((3, h, w), np.int32)
+        for y in range(1, h - 1):
+            for xx in range(1, w - 1):
+                ctr = m[y, xx]
+                if (y + xx) & 1:
+                    horiz = (m[y, xx - 1] + m[y, xx + 1] + 1) >> 1
+                    vert = (m[y - 1, xx] + m[y + 1, xx] + 1) >> 1
+                    o[1, y, xx] = ctr
+                    if y & 1:
+                        o[0, y, xx], o[2, y, xx] = horiz, vert
+                    else:
+                        o[2, y, xx], o[0, y, xx] = horiz, vert
+                else:
+                    cross = (m[y - 1, xx] + m[y, xx - 1] + m[y, xx + 1] + m[y + 1, xx] + 2) >> 2
+                    diag = (m[y - 1, xx - 1] + m[y - 1, xx + 1] + m[y + 1, xx - 1] + m[y + 1, xx + 1] + 2) >> 2
+                    o[1, y, xx] = cross
+                    if y & 1:
+                        o[0, y, xx], o[2, y, xx] = ctr, diag
+                    else:
+                        o[2, y, xx], o[0, y, xx] = ctr, diag
+        o[:, 1:h - 1, 0] = o[:, 1:h - 1, 1]
+        o[:, 1:h - 1, w - 1] = o[:, 1:h - 1, w - 2]
+        o[:, 0, :] = o[:, 1, :]
+        o[:, h - 1, :] = o[:, h - 2, :]
+        out[b] = o.astype(np.uint8)
+    return torch.from_numpy(out).float() / 255.0

@@ -129,3 +129,25 @@ def test_realesrgan_dataset_items(tmp_path):
             for k in ("kernel1", "kernel2", "sinc_kernel"):
                 assert it[k].shape == (21, 21) and abs(it[k].sum().item() - 1) < 1e-4
     assert (ds[1]["gt"] == 0).float().mean() > 0.3                 # zero padding of the small image survives flips / rotations
+
+
+def test_demosaic_oracle_hand_worked_case():
+    """oracle.otf.demosaic_artifacts on a 4x4 image worked by hand (realesrgan_model.py:327-361; cv2's bilinear rule restated, unpinned)."""
+    from oracle import otf as OO
+
+    lv = torch.arange(48, dtype=torch.float32).reshape(1, 3, 4, 4) * 5            # 8-bit levels 0..235, all distinct
+    out = (OO.demosaic_artifacts((lv + 0.4) / 255.0) * 255).round().int()         # +0.4: the uint8 cast truncates
+    ch0, ch1, ch2 = lv[0, 0].int(), lv[0, 1].int(), lv[0, 2].int()
+    m = torch.zeros(4, 4, dtype=torch.int32)
+    m[0::2, 0::2], m[0::2, 1::2], m[1::2, 0::2], m[1::2, 1::2] = ch2[0::2, 0::2], ch1[0::2, 1::2], ch1[1::2, 0::2], ch0[1::2, 1::2]
+    # (1, 1) keeps channel 0; green from the four edge neighbours, channel 2 from the four diagonal ones
+    assert out[0, 0, 1, 1] == m[1, 1]
+    assert out[0, 1, 1, 1] == (m[0, 1] + m[1, 0] + m[1, 2] + m[2, 1] + 2) // 4
+    assert out[0, 2, 1, 1] == (m[0, 0] + m[0, 2] + m[2, 0] + m[2, 2] + 2) // 4
+    # (1, 2) is a green site on an odd row: channel 0 beside it, channel 2 above / below
+    assert out[0, 1, 1, 2] == m[1, 2]
+    assert out[0, 0, 1, 2] == (m[1, 1] + m[1, 3] + 1) // 2
+    assert out[0, 2, 1, 2] == (m[0, 2] + m[2, 2] + 1) // 2
+    # borders repeat the nearest interior pixel
+    assert torch.equal(out[0, :, 0, 0], out[0, :, 1, 1]) and torch.equal(out[0, :, 3, 3], out[0, :, 2, 2])
+    assert torch.equal(out[0, :, 0, 2], out[0, :, 1, 2]) and torch.equal(out[0, :, 2, 0], out[0, :, 2, 1])

@@ -205,7 +205,7 @@ def test_realesrgan_model_trains_on_otf_pairs(cuda):
     with pytest.raises(RuntimeError, match="different batch"):
         model.feed_data({"gt": nxt["gt"], "kernel1": k, "kernel2": k, "sinc_kernel": sinc})
     with pytest.raises(NotImplementedError):
-        build_model(_otf_opt(demosaic_prob=0.5))
+        build_model(_otf_opt(enable_sequences=True))
     model.is_train = False
     model.feed_data({"lq": torch.rand(1, 3, 8, 8), "gt": torch.rand(1, 3, 32, 32)})      # validation batches stay paired
     assert model.lq.shape == (1, 3, 8, 8)
@@ -258,3 +258,43 @@ def test_otf_feed_end_to_end_from_image_files(cuda, tmp_path):
         steps += 1
         model.optimize_parameters(steps, 0, True)
     assert steps == 6 and model.get_current_log()["l_g_l1"] > 0
+
+
+def test_demosaic_stage_is_bit_exact_against_the_oracle(cuda):
+    """tr_bayer_round_trip against oracle.otf.demosaic_artifacts (realesrgan_model.py:312-363).  Byte work: bit-exact.  cv2 is absent, so the oracle's
+    bilinear demosaicing is itself a restatement of OpenCV's published algorithm -- PARITY UNPINNED for this stage; what is pinned here is the
+    reference's own part: the 8-bit truncation, which channel each site keeps, and that kept sites pass through unchanged."""
+    from oracle import otf as OO
+    from trainner_redux_amd.data import otf
+
+    g = torch.Generator().manual_seed(12)
+    for shape in [(2, 3, 16, 16), (1, 3, 7, 9), (3, 3, 3, 3), (1, 3, 34, 21)]:
+        img = torch.rand(shape, generator=g) * 1.2 - 0.1                     # out-of-range values exercise the clamp
+        out = otf.bayer_round_trip(img.to(cuda)).cpu()
+        want = OO.demosaic_artifacts(img)
+        assert torch.equal(out, want), shape
+        q = (img.clamp(0, 1) * 255).to(torch.uint8).float() / 255.0         # img.astype("uint8") truncates
+        h, w = shape[2:]
+        assert torch.equal(out[:, 2, 2:h - 1:2, 2:w - 1:2], q[:, 2, 2:h - 1:2, 2:w - 1:2])       # interior sites keep their own colour
+        assert torch.equal(out[:, 0, 1:h - 1:2, 1:w - 1:2], q[:, 0, 1:h - 1:2, 1:w - 1:2])
+        assert torch.equal(out[:, 1, 1:h - 1:2, 2:w - 1:2], q[:, 1, 1:h - 1:2, 2:w - 1:2])
+    flat = torch.full((1, 3, 8, 8), 0.5)
+    assert torch.equal(otf.bayer_round_trip(flat.to(cuda)).cpu(), torch.full((1, 3, 8, 8), 127 / 255.0))      # a flat field stays flat
+    with pytest.raises(ValueError):
+        otf.bayer_round_trip(torch.rand(1, 1, 8, 8).to(cuda))
+    with pytest.raises(RuntimeError, match="tr_bayer_round_trip"):
+        otf.bayer_round_trip(torch.rand(1, 3, 2, 8).to(cuda))
+
+
+def test_demosaic_gate_runs_in_the_pipeline(cuda):
+    import random
+
+    import numpy as np
+
+    from trainner_redux_amd.data import otf
+
+    deg = otf.OTFDegrader(_otf_opt(demosaic_prob=1.0), rng=np.random.default_rng(1), rnd=random.Random(1))
+    gt = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(3)).to(cuda)
+    ident = torch.zeros(1, 21, 21); ident[:, 10, 10] = 1.0
+    staged = deg._before_codec_stages(gt, ident.to(cuda), ident.to(cuda))
+    assert staged.shape[1] == 3 and torch.isfinite(staged).all()

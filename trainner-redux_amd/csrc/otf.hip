@@ -166,6 +166,44 @@ __global__ __launch_bounds__(256) void color601_kernel(const float* __restrict__
     }
 }
 
+// Demosaicing-artifact stage (realesrgan_model.py:312-363): quantise to 8 bits, keep one colour per site -- channel 2 at (even, even), channel 0 at (odd, odd),
+// channel 1 elsewhere, the reference's mosaic -- and rebuild the other two by OpenCV's bilinear cv2.demosaicing(COLOR_BAYER_BG2BGR) (opencv 4.x
+// imgproc/demosaicing.cpp Bayer2RGB_, restated: 2-neighbour (a + b + 1) >> 1, 4-neighbour (a + b + c + d + 2) >> 2 in integers; the first / last column
+// repeat their inner neighbour, then the first / last row repeat theirs).  One thread per pixel, three outputs; u8 / 255 back to fp32.
+__device__ __forceinline__ int bayer_site(const float* __restrict__ img, int64_t hw, int w, int y, int x) {
+    const int ch = (y & 1) ? ((x & 1) ? 0 : 1) : ((x & 1) ? 1 : 2);
+    const float v = fminf(fmaxf(img[ch * hw + (int64_t)y * w + x], 0.f), 1.f);
+    return (int)(unsigned char)(v * 255.f);
+}
+
+__global__ __launch_bounds__(256) void bayer_round_trip_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int64_t total) {
+    const int64_t hw = (int64_t)h * w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nb = i / hw, p = i - nb * hw;
+        const int y0 = (int)(p / w), x0 = (int)(p - (int64_t)y0 * w);
+        const int y = min(max(y0, 1), h - 2), x = min(max(x0, 1), w - 2);
+        const float* img = src + nb * 3 * hw;
+        const int ctr = bayer_site(img, hw, w, y, x);
+        const int up = bayer_site(img, hw, w, y - 1, x), dn = bayer_site(img, hw, w, y + 1, x);
+        const int lf = bayer_site(img, hw, w, y, x - 1), rt = bayer_site(img, hw, w, y, x + 1);
+        int o[3];
+        if ((y ^ x) & 1) {                                   // green site: the other two colours sit beside it, one pair per axis
+            const int horiz = (lf + rt + 1) >> 1, vert = (up + dn + 1) >> 1;
+            o[1] = ctr;
+            o[(y & 1) ? 0 : 2] = horiz;                      // odd rows hold channel 0 beside the greens, even rows channel 2
+            o[(y & 1) ? 2 : 0] = vert;
+        } else {
+            const int diag = (bayer_site(img, hw, w, y - 1, x - 1) + bayer_site(img, hw, w, y - 1, x + 1) + bayer_site(img, hw, w, y + 1, x - 1) +
+                              bayer_site(img, hw, w, y + 1, x + 1) + 2) >> 2;
+            o[1] = (up + lf + rt + dn + 2) >> 2;
+            o[(y & 1) ? 0 : 2] = ctr;
+            o[(y & 1) ? 2 : 0] = diag;
+        }
+        float* d = dst + nb * 3 * hw + p;
+        d[0] = (float)o[0] / 255.f; d[hw] = (float)o[1] / 255.f; d[2 * hw] = (float)o[2] / 255.f;
+    }
+}
+
 struct Gain4 { float g[4]; };
 __global__ __launch_bounds__(256) void gain_noise_kernel(const float* __restrict__ src, const float* __restrict__ noise, float* __restrict__ dst, int c, int64_t hw,
                                                           int64_t total, Gain4 gain, float noise_std) {
@@ -242,4 +280,11 @@ extern "C" int tr_color601(void* stream, const float* src, float* dst, int n, in
     const int64_t total = (int64_t)n * hw;
     hipLaunchKernelGGL(color601_kernel, dim3(sweep_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, hw, total, mode);
     return tr::launch_status("tr_color601");
+}
+
+extern "C" int tr_bayer_round_trip(void* stream, const float* src, float* dst, int n, int h, int w) {
+    TR_REQUIRE(src && dst && n > 0 && h >= 3 && w >= 3, TR_EINVAL, "tr_bayer_round_trip: bad arguments (3-channel fp32 NCHW, h and w >= 3)");
+    const int64_t total = (int64_t)n * h * w;
+    hipLaunchKernelGGL(bayer_round_trip_kernel, dim3(sweep_grid(total)), dim3(256), 0, (hipStream_t)stream, src, dst, h, w, total);
+    return tr::launch_status("tr_bayer_round_trip");
 }

@@ -299,6 +299,17 @@ def warp_bilinear(img: torch.Tensor, mode: int, params) -> torch.Tensor:
     return out
 
 
+def bayer_round_trip(img: torch.Tensor) -> torch.Tensor:
+    """Demosaicing artifacts (realesrgan_model.py:312-363): 8-bit mosaic + OpenCV-bilinear reconstruction of a 3-channel batch, on the device."""
+    img = img.contiguous().float()
+    b, c, h, w = img.shape
+    if c != 3:
+        raise ValueError("the demosaicing stage indexes three colour channels (realesrgan_model.py:342-345)")
+    out = torch.empty_like(img)
+    L.check(L.lib().tr_bayer_round_trip(stream_ptr(), img.data_ptr(), out.data_ptr(), b, h, w), "tr_bayer_round_trip")
+    return out
+
+
 def motion_blur_kernel(kernel_size: int, angle: float) -> torch.Tensor:
     """models/paragon_otf_degradations.py:276-294."""
     center = kernel_size // 2
@@ -367,14 +378,14 @@ _OTF_DEFAULTS = dict(   # utils/redux_options.py:503-901
     recompression_prob=0, recompression_formats=["jpeg", "webp", "avif", "heif"], recompression_weights=[0.50, 0.35, 0.10, 0.05], editing_prob=0,
     editing_exposure_prob=0, editing_exposure_range=(0.9, 1.1), editing_oversharpen_prob=0, editing_oversharpen_strength=(1.0, 1.3), queue_size=120,
     enable_sequences=False)
-_UNBUILT = ("demosaic_prob",)                      # an OpenCV (cv2) round trip per sample in the reference; cv2 is absent here
+_UNBUILT = ()
 
 
 class OTFDegrader:
     """The training branch of RealESRGANModel.feed_data (models/realesrgan_model.py:456-664), stage for stage and RNG draw for RNG draw
     (numpy Generator = the reference's `RNG.get_rng()`, python `random` for the resize mode / crop / motion-kernel size, torch for the noise
-    field and the pool shuffle), so that a seeded run takes the same decisions.  Stages that are not built (
-    demosaicing artifacts: an OpenCV body) raise at construction when their probability is non-zero."""
+    field and the pool shuffle), so that a seeded run takes the same decisions.  The demosaicing stage (an OpenCV round trip per sample on the
+    host in the reference) runs as one device kernel restating cv2's bilinear demosaicing (cv2 is absent here: that stage's values are unpinned)."""
 
     def __init__(self, opt, rng: np.random.Generator | None = None, rnd=random) -> None:
         self.o = {k: (getattr(opt, k, None) if getattr(opt, k, None) is not None else v) for k, v in _OTF_DEFAULTS.items()}
@@ -418,7 +429,8 @@ class OTFDegrader:
             out = conv_shared_zeropad(out, motion_blur_kernel(ks, angle), ks // 2)
         if self._gate("blur_prob"):
             out = filter2d(out, kernel1)
-        self._gate("demosaic_prob")
+        if self._gate("demosaic_prob"):
+            out = bayer_round_trip(out)
         if self._gate("sensor_noise_prob"):
             std = rng.uniform(o["sensor_noise_std_range"][0], o["sensor_noise_std_range"][1])
             out = gain_noise_clamp(out, 1.0, torch.randn_like(out), std)
