@@ -70,6 +70,7 @@ class PairPool:
 # Resizes are separable gathers (tr_resample_axis) over (index, weight) tables built here on the host -- a few hundred floats per call.
 # ======================================================================================================================================
 import io
+import logging
 import math
 import random
 
@@ -393,7 +394,10 @@ class OTFDegrader:
             if self.o[k]:
                 raise NotImplementedError(f"OTF stage `{k}` > 0 is not built on the HIP path yet")
         if self.o["enable_sequences"]:
-            raise NotImplementedError("OTF degradation sequences (enable_sequences) are not built on the HIP path")
+            # realesrgan_model.py:63-72 builds a SequenceController when this is set and never consults it (no other use in the reference):
+            # the feed is the same stage list either way, so the switch is accepted and changes nothing here either.
+            logging.getLogger("traiNNer").info("enable_sequences: the reference constructs its sequence controller but feed_data never uses it; "
+                                               "the OTF feed runs its fixed stage list")
         seed = getattr(opt, "manual_seed", None)
         self.rng = rng if rng is not None else np.random.default_rng(seed if seed is not None else 0)
         self.rnd = rnd
