@@ -23,7 +23,7 @@ def test_psnr_ssim_match_float64_restatement(cuda, crop, ychan):
     assert calculate_metric({"img": a, "img2": b}, {"type": "calculate_psnr", "crop_border": crop, "test_y_channel": ychan, "better": "higher"}) == p
 
 
-def test_tiled_inference_and_validation_loop(cuda):
+def test_tiled_inference_and_validation_loop(cuda, tmp_path):
     from oracle import esrgan as OE, metrics as OM
     from tests.test_sr_model_gpu import _opt
     from trainner_redux_amd.models import SRModel
@@ -73,3 +73,22 @@ def test_tiled_inference_and_validation_loop(cuda):
     assert model.best_metric_results["toy"]["psnr"] == {"better": "higher", "val": model.metric_results["psnr"], "iter": 100}
     model.validation(loader, 200)
     assert model.best_metric_results["toy"]["ssim"]["iter"] == 200         # ties update (>=), as in the reference
+
+    # image dumps (sr_model.py:1053-1113): <visualization>/<dataset> - <name>/<name>_<iter>.png while training with several val sets,
+    # <visualization>/<dataset>/<name>[_suffix].png when testing; the pixels are tensor2img's round(clamp(x) * 255)
+    import numpy as np
+    from PIL import Image
+
+    vis = tmp_path / "visualization"
+    opt.path.visualization = str(vis)
+    model.validation(loader, 300, save_img=True, multi_val_datasets=True)
+    f = vis / "toy - 1" / "1_000300.png"
+    assert f.exists() and (vis / "toy - 0" / "0_000300.png").exists()
+    want = (model.output[0].float().clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()      # the loader's last item
+    assert np.array_equal(np.asarray(Image.open(f)), want)
+    model.opt.is_train, opt.val.suffix = False, "x4"
+    try:
+        model.validation(loader, 300, save_img=True)
+    finally:
+        model.opt.is_train = True
+    assert np.array_equal(np.asarray(Image.open(vis / "toy" / "1_x4.png")), want)

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 import os
+import os.path as osp
 from collections import OrderedDict
 from typing import Any
 
@@ -89,6 +90,7 @@ class SRModel:
         self.gt: Tensor | None = None
         self.output: Tensor | None = None
         self.with_metrics = False
+        self.first_val_completed = False
         self.metric_results: dict = {}
         self.best_metric_results: dict = {}
         self.training_automation_manager = None
@@ -622,8 +624,9 @@ class SRModel:
             self.nondist_validation(dataloader, current_iter, tb_logger, save_img, multi_val_datasets)
 
     def nondist_validation(self, dataloader, current_iter: int, tb_logger=None, save_img: bool = False, multi_val_datasets: bool = False) -> None:
-        """sr_model.py:960-1139 without the image dump: per validation pair feed_data -> test -> the `val.metrics` on the device;
-        means over the loader in `metric_results`, running best per dataset in `best_metric_results`."""
+        """sr_model.py:960-1139: per validation pair feed_data -> test -> the `val.metrics` on the device; means over the loader in
+        `metric_results`, running best per dataset in `best_metric_results`; with `save_img` the 8-bit SR image goes to the reference's
+        path under `path.visualization` (sr_model.py:1053-1113; PNG through PIL instead of cv2: same pixels)."""
         from ..metrics import calculate_metric
 
         val = self.opt.val
@@ -631,8 +634,10 @@ class SRModel:
         ds = dataloader.dataset
         name = (ds.opt.get("name") if isinstance(getattr(ds, "opt", None), dict) else getattr(getattr(ds, "opt", None), "name", None)) or "val"
         with_metrics = bool(val.metrics_enabled) and val.metrics is not None
-        if save_img:
-            raise NotImplementedError("validation image dumps are not built; metrics only")
+        if save_img and len(dataloader) > 0:
+            if getattr(self.opt.path, "visualization", None) is None:
+                raise ValueError("save_img needs path.visualization (sr_model.py:972)")
+            os.makedirs(self.opt.path.visualization, exist_ok=True)
         if with_metrics:
             if not self.metric_results:
                 self.metric_results = dict.fromkeys(val.metrics.keys(), 0)
@@ -643,6 +648,8 @@ class SRModel:
             self.feed_data(data)
             self.test()
             n += 1
+            if save_img:
+                self._dump_validation_image(data, dataloader, name, current_iter, multi_val_datasets)
             if with_metrics:
                 for key, mopt in val.metrics.items():
                     self.metric_results[key] += calculate_metric({"img": self.output, "img2": self.gt}, mopt)
@@ -653,6 +660,44 @@ class SRModel:
             if tb_logger is not None:
                 for key, v in self.metric_results.items():
                     tb_logger.add_scalar(f"metrics/{name}/{key}", v, current_iter)
+        self.first_val_completed = True
+
+    def _dump_validation_image(self, data, dataloader, dataset_name: str, current_iter: int, multi_val_datasets: bool) -> None:
+        """sr_model.py:1053-1113: where the SR image of one validation item is written; tensor2img's clamp / x255 / round (img_util.py:251-277)."""
+        import shutil
+
+        from PIL import Image
+
+        lq_path = data["lq_path"][0] if isinstance(data.get("lq_path"), (list, tuple)) else data.get("lq_path")
+        if lq_path is None:
+            raise ValueError("save_img needs `lq_path` in the validation batch (sr_model.py:1007)")
+        img_name = osp.splitext(osp.basename(lq_path))[0]
+        vis = self.opt.path.visualization
+        save_dir = None
+        if self.opt.is_train:
+            if multi_val_datasets:
+                save_dir = osp.join(vis, f"{dataset_name} - {img_name}")
+            else:
+                dsopt = getattr(dataloader.dataset, "opt", None)
+                roots = (dsopt.get("dataroot_lq") if isinstance(dsopt, dict) else getattr(dsopt, "dataroot_lq", None))
+                assert roots is not None, "dataroot_lq is required for val set"
+                norm = osp.normpath(lq_path)
+                root = next((r for r in roots if norm.startswith(osp.normpath(r) + osp.sep)), None)
+                if root is None:
+                    raise ValueError(f"The lq_path {lq_path} does not match any of the provided dataroot_lq paths.")
+                save_dir = osp.join(vis, osp.relpath(osp.splitext(lq_path)[0], root))
+            path = osp.join(save_dir, f"{img_name}_{current_iter:06d}.png")
+        elif self.opt.val.suffix:
+            path = osp.join(vis, dataset_name, f"{img_name}_{self.opt.val.suffix}.png")
+        else:
+            path = osp.join(vis, dataset_name, f"{img_name}.png")
+        os.makedirs(osp.dirname(path), exist_ok=True)
+        u8 = (self.output[0].float().clamp(0, 1) * 255.0).round().to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+        Image.fromarray(u8[..., 0] if u8.shape[2] == 1 else u8).save(path)
+        if self.opt.is_train and not self.first_val_completed and osp.exists(lq_path):
+            lr_target = osp.join(save_dir, f"{img_name}_lr.png")
+            if not osp.exists(lr_target):
+                shutil.copy(lq_path, lr_target)
 
     def _initialize_best_metric_results(self, dataset_name: str) -> None:
         """base_model.py:160-173"""
