@@ -7,7 +7,7 @@ import trainner_redux_amd
 from trainner_redux_amd import _lib as L, ops
 
 dev = torch.device("cuda")
-B, hw = 32, 64 * 64
+B, hw = int(os.environ.get("B", "32")), 64 * 64
 shapes = [(192, 540, "f32out"), (192, 540, "cdout"), (192, 180, "f32out+res"), (192, 360, "gelu"), (384, 180, "f32out+res"), (544, 180, "f32out"), (192, 360, "cdout"),
           (384, 180, "cdout")]
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
