@@ -8,6 +8,8 @@ from trainner_redux_amd import _lib as L, ops
 dev = torch.device("cuda")
 shapes = [(16, 256, 256, 64, 32), (16, 256, 256, 96, 32), (16, 256, 256, 128, 32), (16, 256, 256, 160, 32), (16, 256, 256, 192, 64),
           (16, 1024, 1024, 64, 64), (16, 512, 512, 64, 64)]
+if os.environ.get("N"):      # sub-batch A/B: the same layers at another batch size (does the working set fit the 256 MB Infinity Cache?)
+    shapes = [(int(os.environ["N"]),) + sh[1:] for sh in shapes]
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
 cds = [("bf16", L.BF16, torch.bfloat16)] if "f32" not in sys.argv else [("f32", L.F32, torch.float32)]
 for cdn, cd, dt in cds:
