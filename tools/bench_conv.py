@@ -22,7 +22,14 @@ for cdn, cd, dt in cds:
             buf = torch.zeros(ops.packed_bytes(cin, cout, cd), dtype=torch.uint8, device=dev)
             plan = ops.PackPlan(dev); plan.add(wt, buf, cin, cout, cd); plan.run()
             out = torch.empty(n, h, w, cout, device=dev, dtype=dt)
-            f = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=cd, inp=ops.view(x), out=ops.view(out), wpacked=buf, act=L.ACT_LRELU)
+            kw = dict(act=L.ACT_LRELU)
+            if os.environ.get("SIDE") == "mask":        # the dgrad form: LeakyReLU-derivative mask read per output element
+                mk = torch.randn(n, h, w, cout, device=dev).to(dt)
+                kw = dict(mask=ops.view(mk), mask_slope=0.2)
+            elif os.environ.get("SIDE") == "res":       # conv5 / RRDB tail: two residual inputs
+                r1, r2 = torch.randn(n, h, w, cout, device=dev).to(dt), torch.randn(n, h, w, cout, device=dev).to(dt)
+                kw = dict(res1=ops.view(r1), scale1=0.2, res2=ops.view(r2), scale2=0.2)
+            f = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=cd, inp=ops.view(x), out=ops.view(out), wpacked=buf, **kw)
         else:
             gy = torch.randn(n, h, w, cout, device=dev).to(dt)
             ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4, dtype=torch.float32, device=dev)

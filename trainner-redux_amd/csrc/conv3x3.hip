@@ -48,9 +48,20 @@ struct ConvArgs {
     const float* bias;
     int ntx, nty, nchunks, ncg;
     int vec_out, vec_out2, vec_res1, vec_res2, vec_mask;
-    int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores
+    int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores, 8 = row-at-a-time epilogue
 };
 
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, not for its global memory traffic.  __syncthreads() adds a
+// release fence, i.e. s_waitcnt vmcnt(0), and on gfx9 vmcnt counts stores too: at a tile boundary of the persistent loop every wave then
+// sat out the full HBM acknowledgement of the epilogue stores it had just issued (measured: 40 % of the 64 -> 64 kernel at 1024 x 1024).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// s_waitcnt vmcnt(0) as an instruction the compiler's wait-count bookkeeping sees (expcnt / lgkmcnt fields left at "no wait")
+#define TR_WAIT_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
 
 // ---- 9 taps x one K-chunk of MFMAs out of the staged LDS image (hl: halo, wl: weight slab) --------------------------
 // Software pipelined over the 2 * KS * KS (tap, 16-byte slot pair) steps: the operand fragments of step s + 1 are read from LDS
@@ -160,15 +171,13 @@ __device__ __forceinline__ float act_pre_grad(int mode, float m) {   // mask_mod
 // 0.75 of its 2.0 ms).  Each wave therefore transposes one 32-pixel row at a time through a private LDS strip
 // ([pixel][CGW] fp32, rows padded by 16 B against bank conflicts) and then walks it with lane = (pixel, 4-channel
 // segment): residual / mask loads and the stores become 8-16 B per lane over contiguous pixel records.
-template <int NT, int R>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
-                                              int l, bool wave_active, int strip_id = -1) {
+template <int NT, int R, bool SIDE>
+__device__ __forceinline__ void conv_epilogue_impl(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
+                                              int l, bool wave_active, int strip_id) {
     constexpr int CGW = NT * 32;
     constexpr int ROWB = CGW * 4 + 16;
     constexpr int SEGS = CGW / 4;            // 16-byte fp32 segments per pixel
     constexpr int ITER = 32 * SEGS / 64;
-    __syncthreads();                          // every wave is done with the staged operands: LDS is free
-    if (!wave_active || (a.dbg & 4)) return;
     const int lr = l & 31, lh = l >> 5;
     char* strip = smem + (strip_id < 0 ? wv : strip_id) * (32 * ROWB);   // wv: row group of the tile; strip_id: wave (when they differ)
     const bool generic = !(a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_res2 && a.vec_mask);
@@ -239,17 +248,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
                 for (int k = 0; k < 4; ++k) v[k] *= ss;
             }
             if (full && !generic) {
-                if (a.res1.ptr) {
+                if (SIDE && a.res1.ptr) {
                     const float4 rr = tr::view_load4(a.res1, pix, co, true);
                     v[0] = v[0] * a.scale1 + a.rs1 * rr.x; v[1] = v[1] * a.scale1 + a.rs1 * rr.y;
                     v[2] = v[2] * a.scale1 + a.rs1 * rr.z; v[3] = v[3] * a.scale1 + a.rs1 * rr.w;
                 }
-                if (a.res2.ptr) {
+                if (SIDE && a.res2.ptr) {
                     const float4 rr = tr::view_load4(a.res2, pix, co, true);
                     v[0] = v[0] * a.scale2 + a.rs2 * rr.x; v[1] = v[1] * a.scale2 + a.rs2 * rr.y;
                     v[2] = v[2] * a.scale2 + a.rs2 * rr.z; v[3] = v[3] * a.scale2 + a.rs2 * rr.w;
                 }
-                if (a.mask.ptr) {
+                if (SIDE && a.mask.ptr) {
                     const float4 mm = tr::view_load4(a.mask, pix, co, true);
                     if (a.mask_mode == 1) {
                         v[0] *= gelu_grad(mm.x); v[1] *= gelu_grad(mm.y); v[2] *= gelu_grad(mm.z); v[3] *= gelu_grad(mm.w);
@@ -271,9 +280,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
             } else {
                 for (int k = 0; k < 4 && co + k < a.cout; ++k) {
                     float x = v[k];
-                    if (a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + k);
-                    if (a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
-                    if (a.mask.ptr) {
+                    if (SIDE && a.res1.ptr) x = x * a.scale1 + a.rs1 * tr::view_load(a.res1, pix, co + k);
+                    if (SIDE && a.res2.ptr) x = x * a.scale2 + a.rs2 * tr::view_load(a.res2, pix, co + k);
+                    if (SIDE && a.mask.ptr) {
                         const float m = tr::view_load(a.mask, pix, co + k);
                         x *= a.mask_mode ? act_pre_grad(a.mask_mode, m) : (m > 0.f ? 1.f : a.mask_slope);
                     }
@@ -285,6 +294,183 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+}
+
+// Two compiled bodies, picked per launch: without side inputs (residuals, derivative mask) the epilogue issues no global loads, so the compiler
+// places no s_waitcnt vmcnt in its loop.  In the single body every iteration opened with vmcnt(0) -- the conservative wait for a possibly
+// pending residual load -- and vmcnt counts stores on gfx9: each of the 16 store instructions of a tile waited for the HBM acknowledgement
+// of the one before it (40 % of the 64 -> 64 kernel at 1024 x 1024).
+template <int NT, int R>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
+                                              int l, bool wave_active, int strip_id = -1) {
+    __syncthreads();                          // every wave is done with the staged operands: LDS is free
+    if (!wave_active || (a.dbg & 4)) return;
+    if (a.res1.ptr || a.res2.ptr || a.mask.ptr) conv_epilogue_impl<NT, R, true>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active, strip_id);
+    else conv_epilogue_impl<NT, R, false>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active, strip_id);
+}
+
+// ---- epilogue of the persistent 3x3 kernel: all rows of the wave through LDS first, side inputs fetched a chunk ahead --------------------
+// conv_epilogue above walks a row at a time and, with residual / mask inputs, loads each 4-channel piece right where it is used: one global
+// round trip per iteration, 8-16 in a row per tile (measured: the masked dgrad form ran 40-70 % behind the plain conv, the two-residual
+// form at half its rate).  Here the wave first parks all its R accumulator rows in LDS -- the accumulators are dead from then on, which
+// frees the registers -- and then walks the R * ITER pieces in chunks of PF: the raw side pieces of a whole chunk are requested
+// back to back (no conversion, branch-free clamped addresses: nothing in that phase reads a loaded register, so the compiler places
+// no wait inside it), then the chunk is converted, combined and stored.  A tile costs R * ITER / PF round trips instead of R * ITER.
+template <typename RAW>
+__device__ __forceinline__ RAW side_raw4(const tr_view& v, int64_t pix, int c) {   // RAW = uint2: 16-bit views, uint4: fp32 views
+    const int64_t idx = pix * v.cstride + v.coff + c;
+    return *(const RAW*)((const char*)v.ptr + idx * (int64_t)(sizeof(RAW) / 4));
+}
+__device__ __forceinline__ float4 side_cvt4(const tr_view& v, uint2 u) {   // same conversions as tr::view_load4(..., vec = true)
+    float4 r;
+    if (v.dtype == TR_BF16) {
+        r.x = __uint_as_float(u.x << 16); r.y = __uint_as_float(u.x & 0xffff0000u);
+        r.z = __uint_as_float(u.y << 16); r.w = __uint_as_float(u.y & 0xffff0000u);
+    } else {
+        r.x = tr::f16_to_f32((unsigned short)(u.x & 0xffffu)); r.y = tr::f16_to_f32((unsigned short)(u.x >> 16));
+        r.z = tr::f16_to_f32((unsigned short)(u.y & 0xffffu)); r.w = tr::f16_to_f32((unsigned short)(u.y >> 16));
+    }
+    return r;
+}
+__device__ __forceinline__ float4 side_cvt4(const tr_view&, uint4 u) {
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+
+// SIDE: 0 = no side inputs, 1 = all of them 16-bit views (8-byte pieces), 2 = all of them fp32 views (16-byte pieces)
+template <int NT, int R, int SIDE>
+__device__ __forceinline__ void conv_epilogue_rows_impl(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
+                                                        int l) {
+    constexpr int CGW = NT * 32;
+    constexpr int ROWB = CGW * 4 + 16;
+    constexpr int SEGS = CGW / 4;            // 16-byte fp32 segments per pixel
+    constexpr int ITER = 32 * SEGS / 64;     // pieces per lane and row
+    constexpr int PPI = 64 / SEGS;           // pixels one wave-wide piece covers
+    constexpr int PF = (NT == 2 && SIDE != 2) ? 4 : 2;   // pieces per chunk, by the register room next to the staged pieces of the next tile
+    typedef typename std::conditional<SIDE == 2, uint4, uint2>::type raw_t;
+    static_assert(64 % SEGS == 0 && ITER % PF == 0, "a lane keeps its channel segment; chunks do not straddle rows");
+    const int lr = l & 31, lh = l >> 5;
+    char* strip = smem + wv * (R * 32 * ROWB);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (y0 + wv * R + r >= a.h) break;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(strip + (r * 32 + lr) * ROWB + (t * 32 + q * 8 + lh * 4) * 4) =
+                    make_float4(acc[r][t][q * 4 + 0], acc[r][t][q * 4 + 1], acc[r][t][q * 4 + 2], acc[r][t][q * 4 + 3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int seg = l % SEGS, p_lane = l / SEGS;
+    const int co = cg * CGW + seg * 4;
+    if (co >= a.cout) return;                 // cout % 4 == 0 and 4-channel-aligned views on this path (conv_epilogue_rows): whole pieces only
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (co + k < a.cout) bias4[k] = a.bias[co + k];
+    }
+    // read before the loop: a global load inside it would put an s_waitcnt vmcnt(0) -- which also waits for the stores -- into every piece
+    const float ss = a.sample_scale ? a.sample_scale[nb] : 1.f;
+#pragma unroll 1
+    for (int c = 0; c < R * ITER / PF; ++c) {
+        const int r = c / (ITER / PF);
+        const int oy = y0 + wv * R + r;
+        if (oy >= a.h) break;
+        const int i0 = (c - r * (ITER / PF)) * PF;
+        const int64_t rowpix = ((int64_t)nb * a.h + oy) * a.w;
+        raw_t q1[PF], q2[PF], qm[PF];
+        if constexpr (SIDE != 0) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int oxc = min(x0 + (i0 + u) * PPI + p_lane, a.w - 1);        // columns past the image edge re-read the last one
+                if (a.res1.ptr) q1[u] = side_raw4<raw_t>(a.res1, rowpix + oxc, co);
+                if (a.res2.ptr) q2[u] = side_raw4<raw_t>(a.res2, rowpix + oxc, co);
+                if (a.mask.ptr) qm[u] = side_raw4<raw_t>(a.mask, rowpix + oxc, co);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int p = (i0 + u) * PPI + p_lane;
+            const int ox = x0 + p;
+            const float4 raw = *(const float4*)(strip + (r * 32 + p) * ROWB + seg * 16);
+            if (ox >= a.w) continue;
+            const int64_t pix = rowpix + ox;
+            float v[4] = {raw.x + bias4[0], raw.y + bias4[1], raw.z + bias4[2], raw.w + bias4[3]};
+            if (a.act == TR_ACT_LRELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * a.slope;
+            } else if (a.act == TR_ACT_RELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+            }
+            float pre[4] = {v[0], v[1], v[2], v[3]};   // value before GELU / SiLU / Mish: what out2 stores in those modes
+            if (a.act == TR_ACT_GELU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+            } else if (a.act == TR_ACT_SILU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] / (1.f + __expf(-v[k]));
+            } else if (a.act == TR_ACT_MISH) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = tr::mish(v[k]);
+            }
+            if (a.sample_scale) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= ss;
+            }
+            if constexpr (SIDE != 0) {
+                if (a.res1.ptr) {
+                    const float4 rr = side_cvt4(a.res1, q1[u]);
+                    v[0] = v[0] * a.scale1 + a.rs1 * rr.x; v[1] = v[1] * a.scale1 + a.rs1 * rr.y;
+                    v[2] = v[2] * a.scale1 + a.rs1 * rr.z; v[3] = v[3] * a.scale1 + a.rs1 * rr.w;
+                }
+                if (a.res2.ptr) {
+                    const float4 rr = side_cvt4(a.res2, q2[u]);
+                    v[0] = v[0] * a.scale2 + a.rs2 * rr.x; v[1] = v[1] * a.scale2 + a.rs2 * rr.y;
+                    v[2] = v[2] * a.scale2 + a.rs2 * rr.z; v[3] = v[3] * a.scale2 + a.rs2 * rr.w;
+                }
+                if (a.mask.ptr) {
+                    const float4 mm = side_cvt4(a.mask, qm[u]);
+                    if (a.mask_mode == 1) {
+                        v[0] *= gelu_grad(mm.x); v[1] *= gelu_grad(mm.y); v[2] *= gelu_grad(mm.z); v[3] *= gelu_grad(mm.w);
+                    } else if (a.mask_mode == 2) {
+                        v[0] *= silu_grad(mm.x); v[1] *= silu_grad(mm.y); v[2] *= silu_grad(mm.z); v[3] *= silu_grad(mm.w);
+                    } else if (a.mask_mode == 3) {
+                        v[0] *= tr::mish_grad(mm.x); v[1] *= tr::mish_grad(mm.y); v[2] *= tr::mish_grad(mm.z); v[3] *= tr::mish_grad(mm.w);
+                    } else {
+                        v[0] *= mm.x > 0.f ? 1.f : a.mask_slope; v[1] *= mm.y > 0.f ? 1.f : a.mask_slope;
+                        v[2] *= mm.z > 0.f ? 1.f : a.mask_slope; v[3] *= mm.w > 0.f ? 1.f : a.mask_slope;
+                    }
+                }
+            }
+            tr::view_store4(a.out, pix, co, make_float4(v[0], v[1], v[2], v[3]), true);
+            if (a.out2.ptr) {
+                const float sc = a.out2_scale;
+                if (a.act >= TR_ACT_GELU) tr::view_store4(a.out2, pix, co, make_float4(pre[0], pre[1], pre[2], pre[3]), true);
+                else tr::view_store4(a.out2, pix, co, make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc), true);
+            }
+        }
+    }
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvArgs& a, f32x16 (&acc)[R][NT], char* smem, int nb, int y0, int x0, int cg, int wv,
+                                                   int l, bool wave_active) {
+    __syncthreads();                          // every wave is done with the staged operands: LDS is free
+    if (!wave_active || (a.dbg & 4)) return;
+    const bool side = a.res1.ptr || a.res2.ptr || a.mask.ptr;
+    // side inputs present, and how many of them are fp32 views: the chunked body takes them all 16-bit or all fp32
+    const int nside = (a.res1.ptr != nullptr) + (a.res2.ptr != nullptr) + (a.mask.ptr != nullptr);
+    const int wide = (a.res1.ptr && a.res1.dtype == TR_F32) + (a.res2.ptr && a.res2.dtype == TR_F32) + (a.mask.ptr && a.mask.dtype == TR_F32);
+    const bool whole = a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_res2 && a.vec_mask && (a.cout & 3) == 0 && (wide == 0 || wide == nside);
+    if (!whole || (a.dbg & 8)) {       // (dbg 8: A/B switch) unaligned views / ragged channel counts: the row-at-a-time body with its scalar tails (wave wv's strip sits inside its rows area)
+        if (side) conv_epilogue_impl<NT, R, true>(a, acc, smem + wv * ((R - 1) * 32 * (NT * 32 * 4 + 16)), nb, y0, x0, cg, wv, l, wave_active, -1);
+        else conv_epilogue_impl<NT, R, false>(a, acc, smem + wv * ((R - 1) * 32 * (NT * 32 * 4 + 16)), nb, y0, x0, cg, wv, l, wave_active, -1);
+    } else if (!side) conv_epilogue_rows_impl<NT, R, 0>(a, acc, smem, nb, y0, x0, cg, wv, l);
+    else if (wide == 0) conv_epilogue_rows_impl<NT, R, 1>(a, acc, smem, nb, y0, x0, cg, wv, l);
+    else conv_epilogue_rows_impl<NT, R, 2>(a, acc, smem, nb, y0, x0, cg, wv, l);
 }
 
 // ---- variant A: register-staged (global -> VGPR -> LDS), persistent over tiles ------------------------------------------
@@ -389,6 +575,7 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && (CT == TR_BF16 || C
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     TR_ISSUE_LOADS(tile, 0)
+    TR_WAIT_VMEM();    // staging registers are always complete at the top of a chunk (see the wait behind the MFMAs), on every path into it
     while (tile < ntiles) {
         TR_DECODE(tile, cg, nb, y0, x0)
         const bool wave_active = (y0 + wv * R) < a.h;
@@ -418,7 +605,7 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && (CT == TR_BF16 || C
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
         for (int ch = 0; ch < a.nchunks; ++ch) {
-            __syncthreads();   // every wave has finished reading the previous LDS image (or the previous tile's epilogue strips)
+            lds_barrier();     // every wave has finished reading the previous LDS image (or the previous tile's epilogue strips)
 #pragma unroll
             for (int j = 0; j < HALO_IT; ++j)
                 if ((HALO_ITEMS % NTHREADS == 0) || (pp0 + 64 * j < HALO_PIX)) {
@@ -437,14 +624,19 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && (CT == TR_BF16 || C
 #pragma unroll
             for (int j = 0; j < W_IT; ++j)
                 if ((W_ITEMS % NTHREADS == 0) || (tid + j * NTHREADS < W_ITEMS)) *(uint4*)(wl + tid * 16 + j * (NTHREADS * 16)) = wreg[j];
-            __syncthreads();
+            lds_barrier();
             // next pieces go in flight while this chunk's MFMAs run
             if (ch + 1 < a.nchunks) {
                 if constexpr (PRE) TR_ISSUE_LOADS_PRE(cg, ch + 1) else TR_ISSUE_LOADS(tile, ch + 1)
             } else if (next_tile < ntiles) TR_ISSUE_LOADS(next_tile, 0)
             if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R, KS>(hl, wl, acc, wv, lr, lh);
+            // the pieces have had the MFMAs to land: waiting here -- in front of the epilogue at the last chunk, whose pieces belong to the
+            // next tile -- keeps the epilogue's stores out of the wait at the top of the next chunk (vmcnt is one in-order counter)
+            TR_WAIT_VMEM();
         }
-        conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
+        // the 8-row / 32-channel tiling lives on 168 VGPRs (three workgroups per CU): the chunked body's piece arrays spill there
+        if constexpr (NT == 1 && R == 2) conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
+        else conv_epilogue_rows<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
         tile = next_tile;
     }
 #undef TR_ISSUE_LOADS
@@ -566,7 +758,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_kernel_dma(ConvArgs a) {
 template <int CT, int NT, int R, int KS>
 int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
     constexpr size_t stage = (size_t)(4 * R + KS - 1) * (TW + KS - 1) * 64 + (size_t)KS * KS * NT * 32 * 64;
-    constexpr size_t strips = (size_t)4 * 32 * (NT * 32 * 4 + 16);          // epilogue transposition strips
+    constexpr size_t strips = (size_t)4 * R * 32 * (NT * 32 * 4 + 16);      // epilogue transposition strips: all R rows of every wave
     constexpr size_t lds = stage > strips ? stage : strips;
     static bool attr_set = false;
     if (!attr_set) {
