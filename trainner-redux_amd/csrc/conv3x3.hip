@@ -635,7 +635,10 @@ __global__ __launch_bounds__(NTHREADS, (NT == 1 && R == 2 && (CT == TR_BF16 || C
             TR_WAIT_VMEM();
         }
         // the 8-row / 32-channel tiling lives on 168 VGPRs (three workgroups per CU): the chunked body's piece arrays spill there
-        if constexpr (NT == 1 && R == 2) conv_epilogue<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
+        if constexpr (NT == 1 && R == 2) {
+            __syncthreads();
+            if (wave_active && !(a.dbg & 4)) conv_epilogue_impl<NT, R, true>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active, -1);   // one body: a second one spills here
+        }
         else conv_epilogue_rows<NT, R>(a, acc, smem, nb, y0, x0, cg, wv, l, wave_active);
         tile = next_tile;
     }
