@@ -316,6 +316,8 @@ int tr_pixel_shuffle(void* stream, tr_view in, tr_view out, int n, int h, int w,
  *   tr_adamw_ema: p,m,v,ema updated in one pass; grad scaled by min(1, clip/(norm+1e-6)) when
  *   clip > 0 (clip_grad_norm_ semantics), using the device-resident norm (no host sync);
  *   grads are zeroed in the same pass when zero_grad != 0 (optimizer.zero_grad(), sr_model.py:719).
+ *   When grad_norm is given and holds NaN / Inf the step is skipped on the device: p, m, v, ema stay untouched (the reference raises
+ *   "Training failed: NaN/Inf found in loss." before backward, sr_model.py:665-666; the host raises the same error at its next read-back).
  */
 int tr_sumsq(void* stream, const float* x, int64_t numel, float* norm_out, float* partials);
 typedef struct tr_adamw_desc {

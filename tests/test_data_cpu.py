@@ -97,3 +97,25 @@ def test_paired_dataset_errors(tmp_path):
         PairedImageDataset(_opt(tmp_path))
     with pytest.raises(NotImplementedError):
         PairedImageDataset(_opt(tmp_path, io_backend={"type": "lmdb"}))
+
+
+def test_loader_seeding_follows_the_reference_formula():
+    """data/__init__.py:168-178: worker seed = num_workers * rank + worker_id + seed; with no workers the loading process itself is seeded
+    as worker 0 of its rank (= train.py:283's `manual_seed + rank`), so two ranks never draw the same crop / flip stream."""
+    import random
+
+    import numpy as np
+    import torch
+
+    from trainner_redux_amd.data.prefetch import build_dataloader, worker_seed
+
+    assert worker_seed(1024, 8, 3, 5) == 8 * 3 + 5 + 1024
+    ds = torch.utils.data.TensorDataset(torch.zeros(4, 1))
+    draws = []
+    for rank in (0, 1):
+        build_dataloader(ds, 2, 0, seed=77, rank=rank)
+        draws.append((random.random(), float(np.random.rand())))
+    random.seed(77); np.random.seed(77)
+    assert draws[0] == (random.random(), float(np.random.rand()))
+    random.seed(78); np.random.seed(78)
+    assert draws[1] == (random.random(), float(np.random.rand())) and draws[0] != draws[1]

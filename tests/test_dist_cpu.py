@@ -60,6 +60,30 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         return True
 
     assert write() is (True if rank == 0 else None)
+    # checkpoints: the training loop calls model.save() on every rank (train.py), only rank 0 may write (base_model.py `@master_only`)
+    from trainner_redux_amd.models.sr_model import SRModel
+
+    class _Self:                                   # save_network / save_training_state touch nothing of the trainer but its options
+        pass
+
+    tiny = torch.nn.Conv2d(3, 4, 3)
+    SRModel.save_network(_Self(), tiny, os.path.join(out_dir, "ckpt", f"net_g_1.safetensors"))
+    dist.barrier()
+    files = sorted(os.listdir(os.path.join(out_dir, "ckpt")))
+    assert files == ["net_g_1.safetensors"], files          # one writer, one file, and every rank sees it complete
+    from safetensors.torch import load_file
+
+    sd = load_file(os.path.join(out_dir, "ckpt", "net_g_1.safetensors"))
+    assert torch.equal(sd["weight"], tiny.state_dict()["weight"]) if rank == 0 else sd["weight"].shape == tiny.weight.shape
+    assert hasattr(SRModel.save_training_state, "__wrapped__") and hasattr(SRModel.save_network, "__wrapped__")
+    # loader workers: worker k of rank r seeds with num_workers * r + k + seed (data/__init__.py:168-178) -> no two (rank, worker) pairs share a stream
+    from trainner_redux_amd.data.prefetch import worker_seed
+
+    seeds = torch.tensor([worker_seed(1024, 4, rank, k) for k in range(4)])
+    allseeds = [torch.zeros_like(seeds) for _ in range(world)]
+    dist.all_gather(allseeds, seeds)               # test-only collective
+    flat = torch.cat(allseeds).tolist()
+    assert len(set(flat)) == len(flat) and flat[0] == 1024
     dist.barrier()
     dist.destroy_process_group()
 

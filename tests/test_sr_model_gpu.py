@@ -264,6 +264,113 @@ def test_span_step_matches_oracle(cuda):
     assert e_w < 5e-4
 
 
+def test_span_three_steps_fused_sweep_grads_cleared_and_ema_tracks(cuda):
+    """SPAN keeps 40 frozen `eval_conv.*` tensors: they must sit outside the trainable arena so that the fused sweep (AdamW + EMA + zero_grad)
+    runs.  Three steps against the oracle: weights, EMA weights, and an all-zero gradient arena after every step (the wgrad kernels
+    accumulate, so a missed zero_grad shows as a wrong step 2)."""
+    from oracle import losses as OL, span as OSP, step as OS
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], network_g=dict(type="span", feature_channels=16))
+    model = SRModel(opt)
+    hp = OSP.hparams(feature_channels=16, scale=4, norm=False)
+    sd = {k: v.detach().cpu().clone() for k, v in model.net_g.state_dict().items() if k != "no_norm"}
+    params = OrderedDict((k, v.clone().requires_grad_("eval_conv" not in k)) for k, v in sd.items())
+    train = OrderedDict((k, v) for k, v in params.items() if "eval_conv" not in k)
+    parr, garr = model.net_g.flat_parameters()
+    assert parr.numel() == sum((v.numel() + 3) // 4 * 4 for v in train.values())        # the arena holds the trainable tensors only
+    assert model.net_g_ema.ema_arena().numel() == parr.numel()
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in train.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    ema = OS.EMAState(OrderedDict((k, v.data) for k, v in train.items()), beta=0.999, power=0.75, update_after_step=0)
+    for it in range(3):
+        lq, gt = _data(seed=40 + it)
+        _, ld, _, _ = OS.generator_step(train, lambda p, x: OSP.forward({**params, **p}, x, hp), OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, ema)
+        model.feed_data({"lq": lq, "gt": gt})
+        model.optimize_parameters(it + 1, 0, True)
+        assert float(garr.abs().max()) == 0.0, f"gradient arena not cleared after step {it + 1}"
+        assert not model.optimizer_g._group_arenas(model.optimizer_g.param_groups[0])[1], "SPAN parameters fell back to per-tensor launches"
+        log = model.get_current_log()
+        model.reset_current_log()
+        assert abs(log["grad_norm_g"] - float(ld["grad_norm_g"])) < 1e-3 * float(ld["grad_norm_g"]), it
+    sdm = model.net_g.state_dict()
+    e_w = max(rel_l2(sdm[k].detach().cpu(), v.data) for k, v in train.items())
+    sde = model.net_g_ema.ema_model.state_dict()
+    e_e = max(rel_l2(sde[k].detach().cpu(), ema.shadow[k]) for k in train)
+    moved = max(rel_l2(sde[k].detach().cpu(), sd[k]) for k in train)
+    print("span after three steps: weights", e_w, "ema", e_e, "ema moved", moved)
+    assert e_w < 1e-3 and e_e < 1e-3 and moved > 0
+
+
+def test_partial_arena_fallback_still_clears_grads_and_updates_ema(cuda):
+    """A user freezing part of a HIP generator hands the optimizer a partial arena: the per-tensor fallback must still leave a zero gradient
+    arena and a moving EMA (the fused sweep's side effects)."""
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], blocks=1)
+    model = SRModel(opt)
+    frozen = model.net_g.conv_first.weight if hasattr(model.net_g, "conv_first") else next(model.net_g.parameters())
+    frozen.requires_grad_(False)
+    model.optimizers.clear(); model.optimizers_skipped.clear()
+    model.setup_optimizers()
+    parr, garr = model.net_g.flat_parameters()
+    w0 = parr.clone()
+    e0 = model.net_g_ema.ema_arena().clone()
+    for it in range(3):
+        lq, gt = _data(seed=50 + it)
+        model.feed_data({"lq": lq, "gt": gt})
+        model.optimize_parameters(it + 1, 0, True)
+        assert float(garr.abs().max()) == 0.0
+    assert not torch.equal(parr, w0)
+    ema = model.net_g_ema.ema_arena()
+    assert not torch.equal(ema, e0) and torch.isfinite(ema).all()
+    # decay at step 3 of power 0.75: the EMA sits strictly between the initial and the online weights
+    assert float((ema - parr).abs().max()) > 0
+
+
+def test_ema_switch_iter_copies_ema_back_into_the_online_model(cuda):
+    """`ema_switch_iter: 2` (ema-pytorch `update_model_with_ema_every`, sr_model.py:223-234): after the updates of steps 1 and 3 (EMA step
+    counter 0 and 2) the online weights equal the EMA weights; after step 2 they differ."""
+    from trainner_redux_amd.models import SRModel
+    from trainner_redux_amd.utils.options import parse_options_dict
+
+    d = dict(name="t", scale=4, num_gpu=1, path={}, use_amp=False, network_g=dict(type="esrgan", num_blocks=1),
+             train=dict(total_iter=100, ema_decay=0.999, ema_power=0.75, ema_switch_iter=2, optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
+                        losses=[dict(type="l1loss", loss_weight=1.0)]))
+    model = SRModel(parse_options_dict(d))
+    same = []
+    for it in range(3):
+        lq, gt = _data(seed=60 + it)
+        model.feed_data({"lq": lq, "gt": gt})
+        model.optimize_parameters(it + 1, 0, True)
+        same.append(torch.equal(model.net_g.flat_parameters()[0], model.net_g_ema.ema_arena()))
+    assert same == [True, False, True], same
+
+
+def test_non_finite_gradient_norm_leaves_weights_untouched_and_raises_before_saving(cuda, tmp_path):
+    """A NaN batch: the device-side guard of tr_adamw_ema skips the update (weights, moments, EMA unchanged, gradients cleared) and `save`
+    raises the reference's error (sr_model.py:665-666) instead of writing a poisoned checkpoint."""
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], blocks=1)
+    opt.path.models = str(tmp_path / "models")
+    opt.path.training_states = str(tmp_path / "states")
+    model = SRModel(opt)
+    lq, gt = _data(seed=70)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    model.get_current_log()
+    parr, garr = model.net_g.flat_parameters()
+    w1, e1 = parr.clone(), model.net_g_ema.ema_arena().clone()
+    bad = gt.clone()
+    bad[0, 0, 0, 0] = float("nan")
+    model.feed_data({"lq": lq, "gt": bad})
+    model.optimize_parameters(2, 0, True)
+    assert torch.equal(parr, w1) and torch.equal(model.net_g_ema.ema_arena(), e1) and float(garr.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="NaN/Inf found in loss"):
+        model.save(0, 2)
+    assert not (tmp_path / "models").exists() or not any((tmp_path / "models").iterdir())
+
+
 def test_mosr_step_matches_oracle(cuda):
     """MoSR generator behind the trainer (`mosr_t` shape, 4x): one L1 step in fp32 against the oracle's step."""
     from oracle import losses as OL, mosr as OM, step as OS

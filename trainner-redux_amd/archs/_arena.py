@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist")
+_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist", "_frozen_arena")
 
 
 class FlatParamModule(nn.Module):
@@ -31,16 +31,27 @@ class FlatParamModule(nn.Module):
         self._saved = None
         self._trigger = None
 
+    def _frozen_param_names(self) -> set:
+        """Names of parameters that never train (SPAN's exported `eval_conv.*` kernels).  They live in a side buffer so that the trainable
+        arena holds exactly what the optimizer is given: the fused sweep (`tr_adamw_ema`: AdamW + EMA lerp + zero_grad) needs ONE fully
+        covered buffer.  Declared by name, not read from `requires_grad`, so that the EMA twin (every parameter frozen) keeps the layout of
+        the online network."""
+        return set()
+
     def _flatten(self) -> None:
-        ps = self._plist = list(self.parameters())
+        named = list(self.named_parameters())
+        frozen_names = self._frozen_param_names()
+        train = [p for n, p in named if n not in frozen_names]
+        frozen = [p for n, p in named if n in frozen_names]
+        ps = self._plist = train + frozen
         dev = ps[0].device
         offs, total = [], 0
-        for p in ps:
+        for p in train:
             offs.append(total)
             total += (p.numel() + 3) // 4 * 4
         arena = torch.zeros(total, dtype=torch.float32, device=dev)
         garena = torch.zeros(total, dtype=torch.float32, device=dev)
-        for p, o in zip(ps, offs):
+        for p, o in zip(train, offs):
             if p.dtype != torch.float32:
                 raise TypeError("master weights stay float32; select bf16 compute with `compute_dtype`")
             arena[o:o + p.numel()].copy_(p.data.reshape(-1))
@@ -48,6 +59,17 @@ class FlatParamModule(nn.Module):
                 garena[o:o + p.numel()].copy_(p.grad.reshape(-1))
             p.data = arena[o:o + p.numel()].view(p.shape)
             p.grad = garena[o:o + p.numel()].view(p.shape) if p.requires_grad else None
+        if frozen:
+            fo, ft = [], 0
+            for p in frozen:
+                fo.append(ft)
+                ft += (p.numel() + 3) // 4 * 4
+            side = torch.zeros(ft, dtype=torch.float32, device=dev)
+            for p, o in zip(frozen, fo):
+                side[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = side[o:o + p.numel()].view(p.shape)
+                p.grad = None
+            self._frozen_arena = side
         self._arena, self._grad_arena, self._offsets = arena, garena, offs
         self._plan = None
         self._ws = {}
@@ -77,11 +99,11 @@ class FlatParamModule(nn.Module):
             ps = list(self.parameters())
         if self._arena is None or ps[0].data_ptr() != self._arena.data_ptr() or ps[0].device != self._arena.device:
             self._flatten()
-        elif ps[0].requires_grad and (ps[0].grad is None or ps[-1].grad is None or ps[0].grad.data_ptr() != self._grad_arena.data_ptr()):
+        elif ps[0].requires_grad and (ps[0].grad is None or ps[len(self._offsets) - 1].grad is None or ps[0].grad.data_ptr() != self._grad_arena.data_ptr()):
             # optimizer.zero_grad(set_to_none=True) dropped the views: re-attach, zeroed
             self._grad_arena.zero_()
-            for p, o in zip(ps, self._offsets):
-                p.grad = self._grad_arena[o:o + p.numel()].view(p.shape)
+            for p, o in zip(ps, self._offsets):     # the trainable prefix of _plist
+                p.grad = self._grad_arena[o:o + p.numel()].view(p.shape) if p.requires_grad else None
 
     def flat_parameters(self) -> tuple[torch.Tensor, torch.Tensor]:
         """(params arena, grads arena) -- consumed by the fused AdamW/EMA sweep and the gradient all-reduce."""

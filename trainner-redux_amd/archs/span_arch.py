@@ -111,6 +111,9 @@ class SPAN(FlatParamModule):
     def is_norm(self) -> bool:
         return self.no_norm is None
 
+    def _frozen_param_names(self) -> set:
+        return {n for n, _ in self.named_parameters() if ".eval_conv." in n}
+
     def _units(self):
         yield "conv_1", self.conv_1
         for b in range(1, 7):

@@ -28,6 +28,18 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                      float* __restrict__ v, float* __restrict__ ema, int64_t numel, Hyper h,
                                                      const float* __restrict__ gnorm, int zero_grad) {
     float gs = h.inv_scale;                            // GradScaler.unscale_ (1 when no loss scaling is in use)
+    // a non-finite gradient norm (NaN / Inf loss: the reference raises at sr_model.py:665-666 BEFORE backward; here the loss scalars are read
+    // back lazily) must not reach the weights: p, m, v and the EMA stay as they are, only the gradients are cleared.  Wave-uniform branch.
+    const bool poisoned = gnorm != nullptr && !isfinite(gnorm[0]);
+    if (poisoned) {
+        if (zero_grad) {
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (numel >> 2); i += (int64_t)gridDim.x * blockDim.x)
+                ((float4*)g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (blockIdx.x == 0)
+                for (int64_t i = ((numel >> 2) << 2) + threadIdx.x; i < numel; i += blockDim.x) g[i] = 0.f;
+        }
+        return;
+    }
     if (h.clip > 0.f) {
         const float c = h.clip / (gnorm[0] * h.inv_scale + 1e-6f);   // clip_grad_norm_: clamp(max_norm / (total + 1e-6), max = 1)
         gs *= c < 1.f ? c : 1.f;

@@ -61,17 +61,33 @@ class DevicePrefetcher:
         return staged
 
 
-def build_dataloader(dataset, batch_size: int, num_workers: int = 0, sampler=None, seed: int | None = None, prefetch_factor: int = 2):
-    """data/__init__.py:61-178 in one place: pinned batches, worker seeding `seed + worker_id`, drop_last for training."""
+def worker_seed(seed: int, num_workers: int, rank: int, worker_id: int) -> int:
+    """data/__init__.py:172-178 (`worker_init_fn`): `num_workers * rank + worker_id + seed`, so that worker k of every rank draws its own
+    crop / flip / rotation stream."""
+    return num_workers * rank + worker_id + seed
+
+
+def build_dataloader(dataset, batch_size: int, num_workers: int = 0, sampler=None, seed: int | None = None, prefetch_factor: int = 2,
+                     rank: int | None = None):
+    """data/__init__.py:61-178 in one place: pinned batches, the reference's worker seeding (`worker_seed`), drop_last for training.
+    With `num_workers == 0` the loading happens in this process, which is seeded as worker 0 of its rank."""
     import random
 
     import numpy as np
 
+    from ..utils.dist_util import get_dist_info
+
+    if rank is None:
+        rank, _ = get_dist_info()
+
     def init(worker_id):
         if seed is not None:
-            random.seed(seed + worker_id)
-            np.random.seed(seed + worker_id)
+            s = worker_seed(seed, max(num_workers, 1), rank, worker_id)
+            random.seed(s)
+            np.random.seed(s)
 
+    if not num_workers:
+        init(0)
     kw = dict(batch_size=batch_size, shuffle=sampler is None, sampler=sampler, num_workers=num_workers, drop_last=True, pin_memory=True,
               worker_init_fn=init if num_workers else None)
     if num_workers:

@@ -50,6 +50,8 @@ class EMA(nn.Module):
         (0.0 = copy the online weights, None = no update this step)."""
         s = int(self.step)
         self.step += 1
+        n = self.update_model_with_ema_every
+        self._switch_due = bool(n) and s % int(n) == 0
         if s % self.update_every != 0:
             return None
         if s <= self.update_after_step:
@@ -82,7 +84,25 @@ class EMA(nn.Module):
                 be.copy_(bo)
 
     @torch.no_grad()
+    def maybe_update_model_with_ema(self) -> None:
+        """`update_model_with_ema_every` (the trainer's `ema_switch_iter`, sr_model.py:223-234): at the end of every N-th update() ema-pytorch
+        copies the EMA weights back into the online model (`update_model_with_ema_beta` 0 = plain copy, the only value the reference
+        uses).  Call after the lerp of the step `advance()` announced it for."""
+        if not getattr(self, "_switch_due", False):
+            return
+        self._switch_due = False
+        ar = self._arenas()
+        if ar is not None and ar[0].numel() == ar[1].numel():
+            ar[0].copy_(ar[1])
+            return
+        for pe, po in zip(self.ema_model.parameters(), self.model.parameters()):
+            po.data.copy_(pe.data.to(po.device))
+        for be, bo in zip(self.ema_model.buffers(), self.model.buffers()):
+            bo.copy_(be.to(bo.device))
+
+    @torch.no_grad()
     def update(self) -> None:
         d = self.advance()
         if d is not None:
             self._lerp(d)
+        self.maybe_update_model_with_ema()

@@ -29,7 +29,7 @@ from .. import ops
 from ..archs import build_network
 from ..losses import build_loss
 from ..optimizers import AdamW, build_optimizer
-from ..utils.dist_util import allreduce_flat_, get_dist_info
+from ..utils.dist_util import allreduce_flat_, get_dist_info, master_only
 from ..utils.misc import loss_type_to_label
 from .ema import EMA
 
@@ -200,6 +200,7 @@ class SRModel:
         dev = self.device
         self._scal = torch.zeros(64, dtype=torch.float32, device=dev)   # device-resident loss scalars
         self._gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._zero1 = torch.zeros(1, dtype=torch.float32, device=dev)
         self._pending: list = []
 
     def setup_optimizers(self) -> None:
@@ -433,6 +434,9 @@ class SRModel:
                     ops.axpby(ops.view(gv), 1.0 / world, ops.NULL_VIEW, 0.0, ops.view(gv), gv.shape[0])
                 ops.sumsq_norm(garr, scal[GN_G:GN_G + 1])
                 self._gnorm = scal[GN_G:GN_G + 1]
+                # sr_model.py:665-666 raises on a non-finite l_g_total before backward; the total lives on the device here, so it poisons the
+                # norm instead (x * 0 is NaN for NaN / Inf, 0 otherwise) and tr_adamw_ema skips the update on a non-finite norm
+                self._gnorm.addcmul_(total, self._zero1)
                 keys.append("grad_norm_g")
                 idx.append(GN_G)
                 found_inf = False
@@ -446,16 +450,19 @@ class SRModel:
                     if self.net_g_ema is not None:
                         d = self.net_g_ema.advance()
                         ema_arena = self.net_g_ema.ema_arena()
-                        if d is None or ema_arena is None:
-                            ema_arena = None
-                            if d is not None:
-                                self._deferred_ema = d
+                        deferred_ema = None
+                        if d is None:
+                            ema_arena = None                 # no EMA update this step (update_every)
+                        elif ema_arena is None:
+                            deferred_ema = d                 # no arena to fold the lerp into: stand-alone lerp after the optimizer step
                         else:
                             ema_decay = d
                     if isinstance(self.optimizer_g, AdamW):
                         self.optimizer_g.set_step_extras(ema_arena=ema_arena, ema_decay=ema_decay, inv_scale=1.0 / S,
                                                          clip=self.grad_clip_threshold if self.grad_clip else 0.0, grad_norm=self._gnorm)
                         self.optimizer_g.step()
+                        if self.net_g_ema is not None and deferred_ema is not None:
+                            self.net_g_ema._lerp(deferred_ema)
                     else:
                         if S != 1.0:
                             garr.mul_(1.0 / S)
@@ -463,8 +470,10 @@ class SRModel:
                             torch.nn.utils.clip_grad_norm_(net.parameters(), self.grad_clip_threshold)
                         self.optimizer_g.step()
                         garr.zero_()
-                        if self.net_g_ema is not None and ema_arena is not None:
-                            self.net_g_ema._lerp(ema_decay)
+                        if self.net_g_ema is not None and (ema_arena is not None or deferred_ema is not None):
+                            self.net_g_ema._lerp(ema_decay if deferred_ema is None else deferred_ema)
+                    if self.net_g_ema is not None:
+                        self.net_g_ema.maybe_update_model_with_ema()   # ema_switch_iter (sr_model.py:223-234): EMA -> online every N steps
                     if S != 1.0:
                         self._gnorm.mul_(1.0 / S)       # logged norm = after unscale_ (sr_model.py:688-705); stream-ordered after the sweep
                     self.optimizers_skipped[0] = False
@@ -730,7 +739,9 @@ class SRModel:
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         net.load_state_dict(sd, strict=strict)
 
+    @master_only
     def save_network(self, net: nn.Module, path: str, fmt: str = "safetensors") -> None:
+        """base_model.py:395-482 (`@master_only` there too: the loop calls save() on every rank, only rank 0 writes)."""
         sd = {k: v.detach().cpu().contiguous() for k, v in net.state_dict().items()}
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
         if fmt == "safetensors":
@@ -742,6 +753,7 @@ class SRModel:
 
     def save(self, epoch: int, current_iter: int) -> None:
         """EMA net -> models/, raw net_g/net_d -> models/resume_models/ (sr_model.py:1174-1205)."""
+        self._flush_pending()       # a NaN / Inf loss queued since the last read-back must raise before anything is written
         p = self.opt.path
         fmt = self.opt.logger.save_checkpoint_format if self.opt.logger is not None else "safetensors"
         if p.models is None:
@@ -755,9 +767,11 @@ class SRModel:
         if self.net_d is not None:
             self.save_network(self.net_d, os.path.join(p.resume_models or p.models, f"net_d_{current_iter}.{ext}"), fmt)
 
+    @master_only
     def save_training_state(self, epoch: int, current_iter: int) -> None:
         """`{iter}.state` in the reference's layout (base_model.py:713-791): epoch, iter, optimizer and scheduler state dicts (the
         optimizer's are torch.optim.AdamW-compatible per-parameter entries), EMA step, scaler_g / scaler_d under fp16."""
+        self._flush_pending()
         p = self.opt.path
         if p.training_states is None:
             raise ValueError("opt.path.training_states is not set")

@@ -97,12 +97,16 @@ class AdamW(torch.optim.Optimizer):
         for group in self.param_groups:
             b1, b2 = group["betas"]
             arenas, loose = self._group_arenas(group)
+            partial: list = []
             for key, members in arenas.items():
                 pa, ga = members[0][1], members[0][2]
                 covered = sum((p.numel() + 3) // 4 * 4 for p, _, _ in members)
                 st = self._flat.get(key)
                 if covered != pa.numel():
-                    loose.extend(p for p, _, _ in members)  # a partial arena: fall back to per-tensor launches
+                    # a partial arena (some of the network's parameters were not given to this optimizer): per-tensor launches, then the
+                    # two things the fused sweep would have done for the trainer -- zero the gradient arena and lerp the EMA arena
+                    loose.extend(p for p, _, _ in members)
+                    partial.append((pa, ga))
                     continue
                 if st is None:
                     # ONE step tensor shared by every parameter of the arena (state_dict() still reports it per parameter): bumping a
@@ -136,6 +140,12 @@ class AdamW(torch.optim.Optimizer):
                 ops.adamw_ema(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], None, lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"],
                               weight_decay=group["weight_decay"], step=int(st["step"]), clip=self._clip, grad_norm=self._grad_norm,
                               zero_grad=False, inv_scale=self._inv_scale)
+            for pa, ga in partial:
+                ga.zero_()
+                ema = self._ema_arena
+                if ema is not None and ema.numel() == pa.numel() and pa.numel() % 4 == 0:
+                    d = float(self._ema_decay)
+                    ops.axpby(ops.view(ema.view(-1, 4)), d, ops.view(pa.view(-1, 4)), 1.0 - d, ops.view(ema.view(-1, 4)), pa.numel() // 4)
         return loss
 
 
