@@ -328,22 +328,23 @@ def test_partial_arena_fallback_still_clears_grads_and_updates_ema(cuda):
 
 
 def test_ema_switch_iter_copies_ema_back_into_the_online_model(cuda):
-    """`ema_switch_iter: 2` (ema-pytorch `update_model_with_ema_every`, sr_model.py:223-234): after the updates of steps 1 and 3 (EMA step
-    counter 0 and 2) the online weights equal the EMA weights; after step 2 they differ."""
+    """`ema_switch_iter: 3` (ema-pytorch `update_model_with_ema_every`, sr_model.py:223-234).  EMA step counter s = 0, 1: the EMA is a copy of
+    the online weights anyway (update_after_step 0, then the `initted` copy); s = 2: a real lerp, the two differ; s = 3: lerp, then the EMA is
+    copied back into the online model; s = 4: they differ again."""
     from trainner_redux_amd.models import SRModel
     from trainner_redux_amd.utils.options import parse_options_dict
 
     d = dict(name="t", scale=4, num_gpu=1, path={}, use_amp=False, network_g=dict(type="esrgan", num_blocks=1),
-             train=dict(total_iter=100, ema_decay=0.999, ema_power=0.75, ema_switch_iter=2, optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
+             train=dict(total_iter=100, ema_decay=0.999, ema_power=0.75, ema_switch_iter=3, optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
                         losses=[dict(type="l1loss", loss_weight=1.0)]))
     model = SRModel(parse_options_dict(d))
     same = []
-    for it in range(3):
+    for it in range(5):
         lq, gt = _data(seed=60 + it)
         model.feed_data({"lq": lq, "gt": gt})
         model.optimize_parameters(it + 1, 0, True)
         same.append(torch.equal(model.net_g.flat_parameters()[0], model.net_g_ema.ema_arena()))
-    assert same == [True, False, True], same
+    assert same == [True, True, False, True, False], same
 
 
 def test_non_finite_gradient_norm_leaves_weights_untouched_and_raises_before_saving(cuda, tmp_path):
