@@ -18,6 +18,7 @@
 //     epilogue (bias, LeakyReLU/ReLU, two scaled residuals, activation-derivative mask, dual
 //     dtype stores) works on 8/16-byte NHWC vectors.
 #include "common.h"
+#include "conv_args.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -33,23 +34,6 @@ constexpr int TW = 32;        // pixels along x per MFMA tile
 constexpr int HALO_W = TW + 2;   // 3x3 kernels (the LDS-DMA variant is 3x3 only)
 constexpr int NTHREADS = 256;
 
-struct ConvArgs {
-    int n, h, w, hin, win;
-    int ih, iw, shift;   // input extent in output-resolution coordinates, and the origin shift of the 'full' mode
-    int cin, cout;
-    int up;            // 0/1: nearest x2 upsample fused into the load
-    int replicate;
-    int act;
-    float slope, scale1, scale2, rs1, rs2, mask_slope, out2_scale;
-    int mask_mode;                 // 0: multiply by (m > 0 ? 1 : mask_slope) ; 1 / 2 / 3: multiply by gelu'(m) / silu'(m) / mish'(m)
-    const float* sample_scale;     // optional n floats: v *= sample_scale[image] before the first residual (DropPath keep mask)
-    tr_view in, out, out2, res1, res2, mask;
-    const char* wpacked;
-    const float* bias;
-    int ntx, nty, nchunks, ncg;
-    int vec_out, vec_out2, vec_res1, vec_res2, vec_mask;
-    int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores, 8 = row-at-a-time epilogue
-};
 
 
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, not for its global memory traffic.  __syncthreads() adds a
@@ -946,10 +930,15 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     hipStream_t st = (hipStream_t)stream;
     static const int dbg = getenv("TRAINNER_CONV_DBG") ? atoi(getenv("TRAINNER_CONV_DBG")) : 0;
     a.dbg = dbg;
+    a.stamps = getenv("TRAINNER_RING_STAMPS") ? (long long*)strtoull(getenv("TRAINNER_RING_STAMPS"), nullptr, 0) : nullptr;
     a.ntx = (a.w + TW - 1) / TW;
     // Staging variant and tile height.  Measured on MI355X (profiles/): the register-staged kernel at two workgroups per
     // CU beats the LDS-DMA kernel at one (each LDS-DMA piece costs the issuing wave 60-100 cycles and the per-CU DMA rate
     // does not cover a 76 KB stage inside one chunk of MFMAs), so it is the default; TRAINNER_CONV_STAGING=dma selects B.
+    {   // the persistent LDS-DMA ring kernel (conv_ring.hip) takes the large 16-bit 3x3 launches of the RRDB trunk / upsampling tail
+        const int rc = tr::conv3x3_ring(st, a, d);
+        if (rc != -1) return rc;
+    }
     static const bool use_dma = getenv("TRAINNER_CONV_STAGING") && !strcmp(getenv("TRAINNER_CONV_STAGING"), "dma");
     static const int force_r = getenv("TRAINNER_CONV_R") ? atoi(getenv("TRAINNER_CONV_R")) : 0;
     const bool roomy = a.h >= 16 && (int64_t)d->n * ((a.h + 15) / 16) * a.ntx * g.ncg >= 512;

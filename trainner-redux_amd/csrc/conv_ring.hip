@@ -1,0 +1,537 @@
+// 3x3 / stride 1 / pad 1 convolution on NHWC channel-slice views, 16-bit operands: persistent LDS-DMA ring kernel.
+//
+// Contract: include/trainner_hip.h (tr_conv3x3); this is the kernel the RRDB trunk and the upsampling tail of ESRGAN run on
+// (reference arithmetic: traiNNer/archs/scunet_aaf6aa_arch.py:310-384, see conv3x3.hip).  Same packed weight slabs, same MFMA
+// orientation D[cout][pixel] and the same accumulation order as conv3x3_kernel_reg, so the two kernels agree bit for bit.
+//
+// Why a second kernel ("ring kernel"): the register-staged kernel moves every operand global -> VGPR -> LDS
+// with two workgroup barriers per 32-channel chunk and transposes its accumulators through LDS before storing; on the RRDB shapes
+// (K = 9 x 64..192, 32 or 64 output channels) its phases add up instead of overlapping and it sustains 20-30 % of the MFMA peak at
+// 2.2-2.5 TB/s.  Here:
+//   * one workgroup per CU, persistent over tiles (the XCD's tiles are contiguous, so vertical halo overlap hits its L2);
+//   * waves are specialised: NCW consumer waves issue nothing but ds_read + MFMA in the K loop; 4 loader waves move the halo
+//     (and the weight chunk) of chunk j + D straight into LDS with buffer_load ... lds (no VGPR round trip, no ds_write), D chunks
+//     ahead, across tile boundaries: the first chunks of the next tile land while the consumers are in the epilogue;
+//   * ONE raw s_barrier per chunk: the loaders arrive after a counted s_waitcnt vmcnt (chunk j - D + 1 has landed), the consumers
+//     after their last ds_read of the chunk before (its stage may be refilled);
+//   * with WRES the weights of all K chunks of the output group stay resident in LDS for the lifetime of the workgroup
+//     (36-110 KB for the RRDB convs): the ring then carries halo bytes only;
+//   * the epilogue stores straight from the accumulators: v_permlane32_swap pairs turn the MFMA layout (one pixel, four scattered
+//     4-channel quads per lane) into 16 consecutive channels per lane, i.e. 2 (bf16) or 4 (fp32) dwordx4 stores per row and lane --
+//     no LDS transposition, no extra barrier.
+#include "common.h"
+#include "conv_args.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2c;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2c;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2c;
+
+constexpr int TW = 32;
+constexpr int HALO_W = TW + 2;
+constexpr unsigned OOB = 0x7fffff00u;        // beyond any num_records: the buffer load returns 0
+constexpr int LDS_MAX = 160 * 1024;
+
+template <int NT, int R, int NCW, int NLW, int D, bool WRES>
+struct Cfg {
+    static constexpr int TH = R * NCW;
+    static constexpr int HALO_PIX = (TH + 2) * HALO_W;
+    static constexpr int HALO_ITEMS = HALO_PIX * 4;                              // 16-byte slots
+    static constexpr int HALO_BYTES = HALO_ITEMS * 16;
+    static constexpr int HALO_IT = (HALO_ITEMS + 64 * NLW - 1) / (64 * NLW);     // DMA pieces per loader wave and chunk
+    static constexpr int CGW = NT * 32;
+    static constexpr int W_ITEMS = 9 * CGW * 4;
+    static constexpr int W_BYTES = W_ITEMS * 16;
+    static constexpr int W_IT = (W_ITEMS + 64 * NLW - 1) / (64 * NLW);
+    static constexpr int S = D + 1;                                              // ring stages
+    static constexpr int STAGE_BYTES = HALO_BYTES + (WRES ? 0 : W_BYTES);
+    static constexpr int NP = HALO_IT + (WRES ? 0 : W_IT);                       // vmcnt events per loader wave and chunk
+    static constexpr int NTHREADS = (NCW + NLW) * 64;
+    static constexpr int NSTRIP = (NCW * 2 * (32 * (32 * 4 + 16)) <= STAGE_BYTES) ? 2 : 1;   // epilogue strips per consumer wave inside one (consumed) stage
+    static_assert(NCW * NSTRIP * (32 * (32 * 4 + 16)) <= STAGE_BYTES, "the epilogue strips alias one ring stage");
+    static_assert(HALO_ITEMS % 4 == 0 && HALO_ITEMS >= 64 && W_ITEMS % 64 == 0, "piece geometry");
+};
+
+__device__ __forceinline__ unsigned pack2(float a, float b, int dtype) {   // element 0 in the low half; RNE like tr::f32_to_h
+    const f32x2c v = {a, b};
+    if (dtype == TR_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2c));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2c));
+}
+
+// ---- 9 taps x one 32-channel chunk of MFMAs out of a staged halo image (hl) and weight chunk (wl); software pipelined one step ahead ------
+template <int CT, int NT, int R>
+__device__ __forceinline__ void ring_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int row0, int lr, int lh) {
+    constexpr int CGW = NT * 32;
+    constexpr int NSTEP = 18;
+    bf16x8 wa[2][NT], xb[2][R];
+#define TR_RING_FRAGS(BUF, STEP)                                                                                        \
+    {                                                                                                                   \
+        const int tap_ = (STEP) >> 1, ky_ = tap_ / 3, kx_ = tap_ % 3, slot_ = ((STEP) & 1) * 2 + lh;                     \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                 \
+            const int row = tap_ * CGW + t * 32 + lr;                                                                    \
+            wa[BUF][t] = *(const bf16x8*)(wl + row * 64 + ((slot_ ^ ((row >> 2) & 3)) << 4));                            \
+        }                                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                  \
+            const int pp = (row0 + r + ky_) * HALO_W + lr + kx_;                                                         \
+            xb[BUF][r] = *(const bf16x8*)(hl + pp * 64 + ((slot_ ^ ((pp >> 2) & 3)) << 4));                              \
+        }                                                                                                               \
+    }
+    TR_RING_FRAGS(0, 0)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < NSTEP) TR_RING_FRAGS(cur ^ 1, s + 1)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if constexpr (CT == TR_BF16) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][t], xb[cur][r], acc[r][t], 0, 0, 0);
+                else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[cur][t]), __builtin_bit_cast(f16x8, xb[cur][r]), acc[r][t], 0, 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TR_RING_FRAGS
+}
+
+// ---- epilogue: one (row, 32-channel tile) unit of a consumer wave -----------------------------------------------------------------------
+// acc of lane (lr, lh): pixel lr, channels q*8 + lh*4 + j (register q*4 + j).  Storing from that layout puts every lane of a store instruction
+// on its own pixel record; measured (in-kernel stamps, 64 -> 32 at 256^2): 8 such dwordx4 stores per wave cost 6.7k cycles per tile -- more than
+// the tile's MFMAs -- and the same shape of side-input loads as much again: the memory pipeline takes pixel-per-lane accesses at a fraction of
+// the rate of lane-contiguous ones.  So a unit crosses LDS once (fp32, [pixel][32 channels], rows padded by 16 B: conflict-free 16-byte
+// writes and reads) and comes back as lane = (pixel l >> 2 (+16), 8-channel piece l & 3): four neighbouring lanes cover 64 (16-bit) or 128
+// (fp32) contiguous bytes of one pixel record, in the stores and in the residual / mask loads alike.  The strips live in the ring stage the
+// tile's last chunk has just been consumed from (free until the loaders pass the next chunk barrier): no LDS of their own.
+// The bias already sits in the accumulators (they are seeded with it).  Side inputs come in the two shapes of the hot path:
+//   SIDE 1: a 16-bit activation-derivative mask (input-gradient convs of the dense block);   SIDE 2: one or two fp32 residuals (conv5 / trunk);
+// their raw pieces for unit u + 1 are requested before unit u is processed (the first unit's before the MFMAs of the tile's last chunk).
+// FAST (host-checked): 16-bit views have the compute dtype CT, act none / LeakyReLU with slope in [0, 1], SIDE 0 / 1 store 16-bit `out` only,
+// SIDE 2 stores fp32 `out` and optionally 16-bit `out2`; otherwise the run-time-typed body.
+constexpr int STRIP_ROW = 32 * 4 + 16;
+constexpr int STRIP_BYTES = 32 * STRIP_ROW;
+
+template <int SIDE>
+struct SideRaw {
+    uint4 q[SIDE == 0 ? 1 : (SIDE == 1 ? 2 : 8)];   // [pixel half][pieces]: SIDE 1: 1 x 16 B ; SIDE 2: res1 2 x 16 B, res2 2 x 16 B
+};
+
+template <int SIDE>
+__device__ __forceinline__ void side_issue(const ConvArgs& a, SideRaw<SIDE>& raw, int64_t rowpix, int x0, int cobase, int l) {
+    const int co = min(cobase + (l & 3) * 8, a.cout - 8);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int64_t pix = rowpix + min(x0 + (l >> 2) + hf * 16, a.w - 1);      // clamped: loads stay inside the image, stores are masked
+        if constexpr (SIDE == 1) {
+            if (a.mask.dtype == TR_F32) {   // generic body only (FAST masks are 16-bit): keep the sign pattern of 8 fp32 values in 16-bit form
+                const float4* p = (const float4*)((const float*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + co);
+                const float4 m0 = p[0], m1 = p[1];
+                raw.q[hf] = make_uint4((m0.x > 0.f ? 0x3f80u : 0u) | (m0.y > 0.f ? 0x3f800000u : 0u), (m0.z > 0.f ? 0x3f80u : 0u) | (m0.w > 0.f ? 0x3f800000u : 0u),
+                                       (m1.x > 0.f ? 0x3f80u : 0u) | (m1.y > 0.f ? 0x3f800000u : 0u), (m1.z > 0.f ? 0x3f80u : 0u) | (m1.w > 0.f ? 0x3f800000u : 0u));
+            } else {
+                raw.q[hf] = *(const uint4*)((const unsigned short*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + co);
+            }
+        } else if constexpr (SIDE == 2) {
+            const uint4* p1 = (const uint4*)((const float*)a.res1.ptr + pix * a.res1.cstride + a.res1.coff + co);
+            raw.q[hf * 4] = p1[0];
+            raw.q[hf * 4 + 1] = p1[1];
+            if (a.res2.ptr) {
+                const uint4* p2 = (const uint4*)((const float*)a.res2.ptr + pix * a.res2.cstride + a.res2.coff + co);
+                raw.q[hf * 4 + 2] = p2[0];
+                raw.q[hf * 4 + 3] = p2[1];
+            }
+        }
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ unsigned pack2c(float a, float b) {
+    const f32x2c v = {a, b};
+    if constexpr (CT == TR_BF16) return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2c));
+    else return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2c));
+}
+
+// 8 consecutive channels -> a view of any dtype (fp32: 2 x 16 B, 16-bit: 16 B): the generic epilogue body
+__device__ __forceinline__ void store8(const tr_view& v, int64_t pix, int co, const float (&x)[8], float sc) {
+    const int64_t idx = pix * v.cstride + v.coff + co;
+    if (v.dtype == TR_F32) {
+        float4* p = (float4*)((float*)v.ptr + idx);
+        p[0] = make_float4(x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc);
+        p[1] = make_float4(x[4] * sc, x[5] * sc, x[6] * sc, x[7] * sc);
+    } else {
+        uint4* p = (uint4*)((unsigned short*)v.ptr + idx);
+        *p = make_uint4(pack2(x[0] * sc, x[1] * sc, v.dtype), pack2(x[2] * sc, x[3] * sc, v.dtype), pack2(x[4] * sc, x[5] * sc, v.dtype),
+                        pack2(x[6] * sc, x[7] * sc, v.dtype));
+    }
+}
+
+template <int CT, int SIDE, bool FAST>
+__device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& acc, const SideRaw<SIDE>& raw, char* strip, int64_t rowpix, bool rowok, int x0,
+                                                   int cobase, int l) {
+    const int lr = l & 31, lh = l >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *(float4*)(strip + lr * STRIP_ROW + (q * 8 + lh * 4) * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
+    // no wait between the writes and the reads below: one wave's DS instructions execute in issue order, and the compiler keeps the (possibly
+    // aliasing) write -> read order; only the read DATA is waited for
+    const int co = cobase + (l & 3) * 8;
+    float4 rd[2][2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int p = (l >> 2) + hf * 16;
+        rd[hf][0] = *(const float4*)(strip + p * STRIP_ROW + (l & 3) * 32);
+        rd[hf][1] = *(const float4*)(strip + p * STRIP_ROW + (l & 3) * 32 + 16);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int ox = x0 + (l >> 2) + hf * 16;
+        float v[8] = {rd[hf][0].x, rd[hf][0].y, rd[hf][0].z, rd[hf][0].w, rd[hf][1].x, rd[hf][1].y, rd[hf][1].z, rd[hf][1].w};
+        const bool ok = rowok && ox < a.w && co < a.cout && !(a.dbg & 4);      // dbg 4 (TRAINNER_CONV_DBG, timing experiments): no stores
+        const int64_t pix = rowpix + min(ox, a.w - 1);
+        if (a.act == TR_ACT_LRELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= v[i] > 0.f ? 1.f : a.slope;
+        } else if (!FAST && a.act == TR_ACT_RELU) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        if constexpr (SIDE == 2) {
+            const uint4 qa = raw.q[hf * 4], qb = raw.q[hf * 4 + 1];
+            const float rr[8] = {__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w),
+                                 __uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = v[i] * a.scale1 + a.rs1 * rr[i];
+            if (a.res2.ptr) {
+                const uint4 qc = raw.q[hf * 4 + 2], qd = raw.q[hf * 4 + 3];
+                const float r2[8] = {__uint_as_float(qc.x), __uint_as_float(qc.y), __uint_as_float(qc.z), __uint_as_float(qc.w),
+                                     __uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z), __uint_as_float(qd.w)};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = v[i] * a.scale2 + a.rs2 * r2[i];
+            }
+        }
+        if constexpr (SIDE == 1) {
+            const uint4 q = raw.q[hf];
+            const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // m > 0 on the raw 16-bit patterns (bf16 and fp16 alike; activations are finite): sign clear and magnitude non-zero = a positive integer
+                v[2 * k] *= (int)(u[k] << 16) > 0 ? 1.f : a.mask_slope;
+                v[2 * k + 1] *= (int)u[k] > 0xffff ? 1.f : a.mask_slope;
+            }
+        }
+        if constexpr (FAST) {
+            if constexpr (SIDE == 2) {
+                if (ok) {
+                    float4* po = (float4*)((float*)a.out.ptr + pix * a.out.cstride + a.out.coff + co);
+                    po[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    po[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+                if (a.out2.ptr) {
+                    const float sc = a.out2_scale;
+                    const uint4 pk = make_uint4(pack2c<CT>(v[0] * sc, v[1] * sc), pack2c<CT>(v[2] * sc, v[3] * sc), pack2c<CT>(v[4] * sc, v[5] * sc), pack2c<CT>(v[6] * sc, v[7] * sc));
+                    if (ok) *(uint4*)((unsigned short*)a.out2.ptr + pix * a.out2.cstride + a.out2.coff + co) = pk;
+                }
+            } else {
+                const uint4 pk = make_uint4(pack2c<CT>(v[0], v[1]), pack2c<CT>(v[2], v[3]), pack2c<CT>(v[4], v[5]), pack2c<CT>(v[6], v[7]));
+                if (ok) *(uint4*)((unsigned short*)a.out.ptr + pix * a.out.cstride + a.out.coff + co) = pk;
+            }
+        } else if (ok) {
+            store8(a.out, pix, co, v, 1.f);
+            if (a.out2.ptr) store8(a.out2, pix, co, v, a.out2_scale);
+        }
+    }
+}
+
+// diagnostics: wave-uniform time stamp into a[stamps]; slot layout [workgroup][role 0 consumer / 1 loader][256 stamps]
+#define TR_STAMP(ROLE)                                                                                                  \
+    if (a.stamps && l == 0 && (ROLE == 0 ? wv == 0 : wv == NCW) && nst < 256)                                           \
+        a.stamps[((int64_t)blockIdx.x * 2 + ROLE) * 256 + nst++] = (long long)__builtin_amdgcn_s_memtime();
+
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI>
+__global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_ring_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int SIDE = EPI % 3;          // side-input shape; EPI < 3: the fast epilogue forms (ring_epilogue_row_fast)
+    constexpr bool FAST = EPI < 3;
+    typedef Cfg<NT, R, NCW, NLW, D, WRES> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = l & 31, lh = l >> 5;
+    int nst = 0;
+
+    // tile walk: workgroup b takes tiles first + k * grid.  Ids are dealt so that the workgroups of one XCD (ids equal mod 8 under
+    // round-robin placement: speed only) own runs of consecutive tiles, i.e. vertically adjacent tiles whose halos overlap.
+    const int G = gridDim.x;
+    const int ntiles = a.ntx * a.nty * a.n * a.ncg;
+    int b = blockIdx.x;
+    if ((G & 7) == 0) b = (b & 7) * (G >> 3) + (b >> 3);
+    const int nmine = (ntiles - b + G - 1) / G;
+    const int total = nmine * a.nchunks;
+    char* ring = smem + (WRES ? a.nchunks * C::W_BYTES : 0);
+    const int64_t in_pix_bytes = (int64_t)a.in.cstride * 2;
+
+#define TR_RING_DECODE(K, CG, NB, Y0, X0)                                                                               \
+    int CG, NB, Y0, X0;                                                                                                 \
+    {                                                                                                                   \
+        int t_ = b + (K) * G;                                                                                           \
+        CG = t_ % a.ncg; t_ /= a.ncg;                                                                                    \
+        X0 = (t_ % a.ntx) * TW; t_ /= a.ntx;                                                                             \
+        Y0 = (t_ % a.nty) * C::TH;                                                                                       \
+        NB = t_ / a.nty;                                                                                                 \
+    }
+
+    if (wv >= NCW) {
+        // =================================================== loader waves ===================================================
+        const int lw = wv - NCW;
+        const unsigned img_bytes = (unsigned)((int64_t)a.hin * a.win * in_pix_bytes);
+        const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpacked, 0, (unsigned)((int64_t)a.ncg * a.nchunks * C::W_BYTES), 0x00020000);
+        if constexpr (WRES) {
+            // all K chunks of output group 0 (WRES launches have ncg == 1), once: older than every halo piece, so the first counted wait covers them
+            const int npieces = a.nchunks * (C::W_ITEMS / 64);
+            for (int p = lw; p < npieces; p += NLW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(smem + p * 1024), 16, (unsigned)(p * 1024 + l * 16), 0, 0, 0);
+        }
+        unsigned hoff[C::HALO_IT];
+        int cgk = 0;
+        __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in.ptr, 0, img_bytes, 0x00020000);
+        int k = 0, ch = 0;
+        int cch = 0;          // the consumers' chunk-in-tile counter, D - 1 iterations behind: the loaders join the per-tile epilogue barrier
+        bool tile_end = false;
+        for (int j = 0; j < total + D - 1; ++j) {
+            if (j < total) {
+                if (ch == 0) {
+                    TR_RING_DECODE(k, cg, nb, y0, x0)
+                    cgk = cg;
+                    in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * a.hin * a.win * in_pix_bytes), 0, img_bytes, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < C::HALO_IT; ++i) {
+                        int p0 = (i * NLW + lw) * 64;
+                        p0 = p0 < C::HALO_ITEMS - 64 ? p0 : C::HALO_ITEMS - 64;     // the tail piece re-fetches the end of the image (duplicates are benign)
+                        const int P = p0 + l;
+                        const int pp = P >> 2;
+                        const int s = (P & 3) ^ ((pp >> 2) & 3);                    // bank swizzle on the SOURCE: the LDS image is position-linear
+                        const int py = pp / HALO_W, px = pp - py * HALO_W;
+                        int oy = y0 + py - 1 - a.shift, ox = x0 + px - 1 - a.shift;
+                        bool ok = (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);
+                        if (a.replicate) {
+                            oy = min(max(oy, 0), a.ih - 1);
+                            ox = min(max(ox, 0), a.iw - 1);
+                            ok = true;
+                        }
+                        const unsigned off = (unsigned)(((int64_t)(oy >> a.up) * a.win + (ox >> a.up)) * in_pix_bytes + (int64_t)(a.in.coff + s * 8) * 2);
+                        hoff[i] = ok ? off : OOB;
+                    }
+                }
+                char* st = ring + (j % C::S) * C::STAGE_BYTES;
+#pragma unroll
+                for (int i = 0; i < C::HALO_IT; ++i) {
+                    int p0 = (i * NLW + lw) * 64;
+                    p0 = p0 < C::HALO_ITEMS - 64 ? p0 : C::HALO_ITEMS - 64;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(st + p0 * 16), 16, hoff[i], ch * 64, 0, 0);
+                }
+                if constexpr (!WRES) {
+                    const unsigned wbase = (unsigned)((cgk * a.nchunks + ch) * C::W_BYTES);
+#pragma unroll
+                    for (int i = 0; i < C::W_IT; ++i) {
+                        int p0 = (i * NLW + lw) * 64;
+                        p0 = p0 < C::W_ITEMS - 64 ? p0 : C::W_ITEMS - 64;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(st + C::HALO_BYTES + p0 * 16), 16,
+                                                                 (unsigned)(p0 * 16 + l * 16), wbase, 0, 0);
+                    }
+                }
+                if (++ch == a.nchunks) { ch = 0; ++k; }
+                if (tile_end) __builtin_amdgcn_s_barrier();      // the consumers' "stage is free for the strips" barrier of the tile that ended in iteration j - 1
+                TR_STAMP(1)
+                // chunk j - (D - 1) has landed once at most (D - 1) chunks of this wave's pieces are outstanding
+                if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NP) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NP) : "memory");
+            } else {
+                if (tile_end) __builtin_amdgcn_s_barrier();
+                TR_STAMP(1)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            TR_STAMP(1)
+            __builtin_amdgcn_s_barrier();
+            TR_STAMP(1)
+            tile_end = false;
+            if (j >= D - 1 && ++cch == a.nchunks) { cch = 0; tile_end = true; }
+        }
+        if (tile_end) __builtin_amdgcn_s_barrier();              // the last tile's epilogue barrier
+        return;
+    }
+
+    // ===================================================== consumer waves =====================================================
+    // the bias seeds the accumulators (no add in the epilogue): all output groups, zero padded, in LDS behind the ring
+    float* bias_lds = (float*)(ring + C::S * C::STAGE_BYTES);
+    for (int i = tid; i < a.ncg * C::CGW; i += NCW * 64) bias_lds[i] = (a.bias && i < a.cout) ? a.bias[i] : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // visible to the other consumer waves behind the first barrier
+    f32x16 acc[R][NT];
+    SideRaw<SIDE> raw[2];
+    int k = 0, ch = 0;
+    int cg = 0, nb = 0, y0 = 0, x0 = 0;
+    for (int j = 0; j < total + D - 1; ++j) {
+        TR_STAMP(0)
+        __builtin_amdgcn_s_barrier();
+        TR_STAMP(0)
+        if (j < D - 1) continue;
+        if (ch == 0) {
+            TR_RING_DECODE(k, cg_, nb_, y0_, x0_)
+            cg = cg_; nb = nb_; y0 = y0_; x0 = x0_;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *(const float4*)(bias_lds + cg * C::CGW + t * 32 + q * 8 + lh * 4);   // accumulator register q*4 + j <-> channel q*8 + lh*4 + j
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[r][t][q * 4 + 0] = b4.x; acc[r][t][q * 4 + 1] = b4.y; acc[r][t][q * 4 + 2] = b4.z; acc[r][t][q * 4 + 3] = b4.w;
+                    }
+                }
+        }
+        const int c = j - (D - 1);
+        const char* st = ring + (c % C::S) * C::STAGE_BYTES;
+        const char* wl = WRES ? smem + ch * C::W_BYTES : st + C::HALO_BYTES;
+        const bool last = ch + 1 == a.nchunks;
+        // pixel of this lane in row r of the wave (clamped to the image: loads stay in range, stores are masked by `ok`)
+        const int64_t rowbase = (int64_t)nb * a.h;
+        if (SIDE != 0 && last) side_issue<SIDE>(a, raw[0], (rowbase + min(y0 + wv * R, a.h - 1)) * a.w, x0, cg * C::CGW, l);
+        ring_chunk_mfma<CT, NT, R>(st, wl, acc, wv * R, lr, lh);
+        TR_STAMP(0)
+        if (last) {
+            ch = 0;
+            ++k;
+            // every consumer wave is done with the stage of this chunk: its bytes become the epilogue strips (two per wave).  The loaders join this
+            // barrier right after issuing their next chunk, which goes to another stage (S >= 2).
+            __builtin_amdgcn_s_barrier();
+            TR_STAMP(0)
+            char* strips = const_cast<char*>(st) + wv * (C::NSTRIP * STRIP_BYTES);
+#pragma unroll
+            for (int u = 0; u < R * NT; ++u) {
+                const int r = u / NT, t = u % NT;
+                const int oy = y0 + wv * R + r;
+                if (SIDE != 0 && u + 1 < R * NT) {
+                    const int r1 = (u + 1) / NT, t1 = (u + 1) % NT;
+                    side_issue<SIDE>(a, raw[(u + 1) & 1], (rowbase + min(y0 + wv * R + r1, a.h - 1)) * a.w, x0, cg * C::CGW + t1 * 32, l);
+                }
+                ring_epilogue_unit<CT, SIDE, FAST>(a, acc[r][t], raw[u & 1], strips + (u % C::NSTRIP) * STRIP_BYTES, (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, x0,
+                                                   cg * C::CGW + t * 32, l);
+            }
+        } else {
+            ++ch;
+        }
+    }
+#undef TR_RING_DECODE
+#endif
+}
+
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI>
+int launch_ring_side(hipStream_t st, const ConvArgs& a) {
+    typedef Cfg<NT, R, NCW, NLW, D, WRES> C;
+    const size_t lds = (size_t)C::S * C::STAGE_BYTES + (WRES ? (size_t)a.nchunks * C::W_BYTES : 0) + (size_t)a.ncg * C::CGW * 4;   // ring + resident weights + bias
+    if (lds > (size_t)(LDS_MAX / WGS)) return -1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (ncu <= 0) ncu = 256;
+    }
+    const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * a.ncg;
+    const unsigned grid = (unsigned)(ntiles < (int64_t)ncu * WGS ? ntiles : (int64_t)ncu * WGS);
+    hipLaunchKernelGGL((conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI>), dim3(grid), dim3(C::NTHREADS), lds, st, a);
+    return tr::launch_status("tr_conv3x3(ring)");
+}
+
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES>
+int launch_ring(hipStream_t st, const ConvArgs& a, int epi) {
+    switch (epi) {
+        case 0: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 0>(st, a);
+        case 1: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 1>(st, a);
+        case 2: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 2>(st, a);
+        case 3: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 3>(st, a);
+        case 4: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 4>(st, a);
+        default: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 5>(st, a);
+    }
+}
+
+bool vec16_ok(const tr_view& v) {   // 16 consecutive channels of a record as 16-byte pieces
+    if (!v.ptr) return true;
+    const int per = 16 / tr::esize(v.dtype);
+    return (v.cstride % per == 0) && (v.coff % per == 0) && (((uintptr_t)v.ptr) % 16 == 0);
+}
+
+}  // namespace
+
+namespace tr {
+
+int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
+    const char* impl = getenv("TRAINNER_CONV_IMPL");   // read per call: tests and A/B tools flip it inside one process          // "reg": never ; "ring": whenever eligible ; unset: eligible and large enough
+    if (impl && !strcmp(impl, "reg")) return -1;
+    const bool force = impl && !strcmp(impl, "ring");
+    if (d->ksize != 3 || (d->compute != TR_BF16 && d->compute != TR_F16)) return -1;
+    if (d->in_mode == TR_IN_VALID || d->in_mode == TR_IN_FULL) return -1;
+    if (d->cin % 32 != 0 || d->cout % 8 != 0) return -1;
+    if (d->act != TR_ACT_NONE && d->act != TR_ACT_LRELU && d->act != TR_ACT_RELU) return -1;
+    if (d->mask_mode != 0 || d->sample_scale || d->cout > 1024) return -1;
+    int side = 0;                                                    // the two side-input shapes of the hot path (ring_epilogue_row)
+    if (d->mask.ptr && !d->res1.ptr && !d->res2.ptr) side = 1;
+    else if (d->res1.ptr && d->res1.dtype == TR_F32 && !d->mask.ptr && (!d->res2.ptr || d->res2.dtype == TR_F32)) side = 2;
+    else if (d->mask.ptr || d->res1.ptr || d->res2.ptr) return -1;
+    // fast epilogue forms (ring_epilogue_row_fast); everything else eligible takes the generic body (epi = side + 3)
+    const int ct = d->compute;
+    const bool lrelu_ok = d->act == TR_ACT_NONE || (d->act == TR_ACT_LRELU && d->slope >= 0.f && d->slope <= 1.f);
+    bool fast = false;
+    if (side == 0) fast = lrelu_ok && d->out.dtype == ct && !d->out2.ptr;
+    else if (side == 1) fast = d->act == TR_ACT_NONE && d->out.dtype == ct && d->mask.dtype == ct && !d->out2.ptr;
+    else fast = d->act == TR_ACT_NONE && d->out.dtype == TR_F32 && (!d->out2.ptr || d->out2.dtype == ct);
+    if (getenv("TRAINNER_RING_GENERIC")) fast = false;               // A/B switch
+    const int epi = fast ? side : side + 3;
+    if (!vec16_ok(d->out) || !vec16_ok(d->out2) || !vec16_ok(d->res1) || !vec16_ok(d->res2) || !vec16_ok(d->mask)) return -1;
+    if ((int64_t)a.hin * a.win * d->in.cstride * 2 >= (int64_t)0x7fff0000) return -1;            // buffer addressing: one image below 2 GiB
+    const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);
+    if ((int64_t)g.ncg * g.nchunks * 9 * g.cgw * 64 >= (int64_t)0x7fff0000) return -1;
+    const int cfg_env = getenv("TRAINNER_RING_CFG") ? atoi(getenv("TRAINNER_RING_CFG")) : -1;
+    const bool bf = d->compute == TR_BF16;
+    const int64_t npix = (int64_t)a.n * a.h * a.w;
+    if (!force && npix < 256 * 512) return -1;                       // fewer than ~one 16 x 32 tile per CU: the register-staged kernel's smaller tiles fill the chip better
+    a.ntx = (a.w + TW - 1) / TW;
+#define TR_RING_LAUNCH(NT, R, NCW, NLW, WGS, D, WRES)                                                                   \
+    {                                                                                                                   \
+        a.nty = (a.h + (R) * (NCW) - 1) / ((R) * (NCW));                                                                 \
+        const int rc = bf ? launch_ring<TR_BF16, NT, R, NCW, NLW, WGS, D, WRES>(st, a, epi) : launch_ring<TR_F16, NT, R, NCW, NLW, WGS, D, WRES>(st, a, epi); \
+        if (rc != -1) return rc;                                                                                        \
+    }
+    // cfg (TRAINNER_RING_CFG, A/B experiments).  32-wide groups: 10 / 11 / 13 resident weights (16-row D 2, 16-row D 1, 8-row D 2), 0 streamed
+    // weights 16-row, 20 two workgroups per CU (8-row tiles, 2 loader waves, streamed weights).  64-wide groups: 0 16-row, 1 8-row, 2 eight consumers.
+    if (g.cgw == 32) {
+        const int cfg = cfg_env >= 0 ? cfg_env : 10;
+        if (cfg == 20) TR_RING_LAUNCH(1, 2, 4, 2, 2, 1, false)
+        if (g.ncg == 1 && cfg >= 10) {
+            if (cfg == 10) TR_RING_LAUNCH(1, 4, 4, 4, 1, 2, true)
+            if (cfg == 10 || cfg == 11) TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, true)
+            TR_RING_LAUNCH(1, 2, 4, 4, 1, 2, true)
+        }
+        TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false)
+    } else {
+        const int cfg = cfg_env >= 0 ? cfg_env % 10 : 0;
+        if (cfg == 1) TR_RING_LAUNCH(2, 2, 4, 4, 1, 1, false)
+        if (cfg == 2) TR_RING_LAUNCH(2, 2, 8, 4, 1, 1, false)
+        TR_RING_LAUNCH(2, 4, 4, 4, 1, 1, false)
+    }
+#undef TR_RING_LAUNCH
+    return -1;
+}
+
+}  // namespace tr
