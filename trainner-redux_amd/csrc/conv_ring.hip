@@ -23,6 +23,7 @@
 #include "conv_args.h"
 #include <stdlib.h>
 #include <string.h>
+#include <utility>
 
 namespace {
 
@@ -38,7 +39,7 @@ constexpr int HALO_W = TW + 2;
 constexpr unsigned OOB = 0x7fffff00u;        // beyond any num_records: the buffer load returns 0
 constexpr int LDS_MAX = 160 * 1024;
 
-template <int NT, int R, int NCW, int NLW, int D, bool WRES>
+template <int NT, int R, int NCW, int NLW, int D, bool WRES, bool PIPE = false>
 struct Cfg {
     static constexpr int TH = R * NCW;
     static constexpr int HALO_PIX = (TH + 2) * HALO_W;
@@ -54,7 +55,10 @@ struct Cfg {
     static constexpr int NP = HALO_IT + (WRES ? 0 : W_IT);                       // vmcnt events per loader wave and chunk
     static constexpr int NTHREADS = (NCW + NLW) * 64;
     static constexpr int NSTRIP = (NCW * 2 * (32 * (32 * 4 + 16)) <= STAGE_BYTES) ? 2 : 1;   // epilogue strips per consumer wave inside one (consumed) stage
-    static_assert(NCW * NSTRIP * (32 * (32 * 4 + 16)) <= STAGE_BYTES, "the epilogue strips alias one ring stage");
+    static_assert(PIPE || NCW * NSTRIP * (32 * (32 * 4 + 16)) <= STAGE_BYTES, "the epilogue strips alias one ring stage");
+    static constexpr int STRIPS_BYTES = PIPE ? NCW * (32 * (32 * 4 + 16)) : 0;               // pipelined kernels: one strip per consumer wave, LDS of its own
+    static constexpr int U = R * NT;                                                         // epilogue units per wave and tile
+    static constexpr int EC = (U + 1 + 4) / 5;                                               // chunks of the NEXT tile the U + 1 epilogue stages are spread over (<= 5 hook slots per chunk)
     static_assert(HALO_ITEMS % 4 == 0 && HALO_ITEMS >= 64 && W_ITEMS % 64 == 0, "piece geometry");
 };
 
@@ -64,29 +68,67 @@ __device__ __forceinline__ unsigned pack2(float a, float b, int dtype) {   // el
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2c));
 }
 
-// ---- 9 taps x one 32-channel chunk of MFMAs out of a staged halo image (hl) and weight chunk (wl); software pipelined one step ahead ------
-template <int CT, int NT, int R>
-__device__ __forceinline__ void ring_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], int row0, int lr, int lh) {
+// ---- 9 taps x one 32-channel chunk of MFMAs out of a staged halo image and weight chunk; software pipelined one step ahead ---------------
+// LDS addressing: the halo image holds pixel (py, px) at (py * HALO_W + px) * 64 with its four 16-byte slots XOR-swizzled by (px >> 2) & 3 -- by the
+// column only, so the address of an operand fragment is  [stage + first row of the wave] + lane term (kx, k-half) + (r + ky) * HALO_W * 64:
+// six lane terms for the nine taps, everything else an immediate offset (a swizzle by the linear pixel index cost an address computation per
+// fragment and ~40 VGPRs).  A wave's ds_read_b128 covers 32 consecutive pixels of one row: conflict free for any kx (the four lanes of a
+// 16-lane group that share px mod 4 have px >> 2 = m, m + 3, m + 5, m + 6: distinct mod 4).  The weight rows keep pack.hip's swizzle, which
+// depends on the lane only (tap * CGW + t * 32 is a multiple of 32).
+struct FragAddr {
+    int hx[3][2];     // [kx][k-half]: (lr + kx) * 64 + (((half * 2 + lh) ^ (((lr + kx) >> 2) & 3)) << 4)
+    int wx[2];        // [k-half]:     lr * 64 + (((half * 2 + lh) ^ ((lr >> 2) & 3)) << 4)
+};
+__device__ __forceinline__ FragAddr make_frag_addr(int lr, int lh) {
+    FragAddr f;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) f.hx[kx][hf] = (lr + kx) * 64 + (((hf * 2 + lh) ^ (((lr + kx) >> 2) & 3)) << 4);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) f.wx[hf] = lr * 64 + (((hf * 2 + lh) ^ ((lr >> 2) & 3)) << 4);
+    return f;
+}
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// The same chunk with NH hook slots between its MFMA steps (slot i behind step 1 + i * HS): `hook(integral_constant<HB + i>)` carries one
+// stage of the PREVIOUS tile's epilogue (pipelined kernels), whose VALU / LDS / store instructions then issue in the shadow of the MFMAs.
+template <int CT, int NT, int R, int HB, int NH, typename HookF>
+__device__ __forceinline__ void ring_chunk_mfma_hooked(const char* hl, const char* wl, f32x16 (&acc)[R][NT], const FragAddr& fa, HookF&& hook) {
     constexpr int CGW = NT * 32;
     constexpr int NSTEP = 18;
+    constexpr int HS = NH > 1 ? 16 / (NH - 1) : 16;
     bf16x8 wa[2][NT], xb[2][R];
-#define TR_RING_FRAGS(BUF, STEP)                                                                                        \
-    {                                                                                                                   \
-        const int tap_ = (STEP) >> 1, ky_ = tap_ / 3, kx_ = tap_ % 3, slot_ = ((STEP) & 1) * 2 + lh;                     \
-        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                                 \
-            const int row = tap_ * CGW + t * 32 + lr;                                                                    \
-            wa[BUF][t] = *(const bf16x8*)(wl + row * 64 + ((slot_ ^ ((row >> 2) & 3)) << 4));                            \
-        }                                                                                                               \
-        _Pragma("unroll") for (int r = 0; r < R; ++r) {                                                                  \
-            const int pp = (row0 + r + ky_) * HALO_W + lr + kx_;                                                         \
-            xb[BUF][r] = *(const bf16x8*)(hl + pp * 64 + ((slot_ ^ ((pp >> 2) & 3)) << 4));                              \
-        }                                                                                                               \
-    }
-    TR_RING_FRAGS(0, 0)
+    // hl: stage + (first halo row of the wave) * HALO_W * 64
+    const char* hb[3][2];
+    const char* wb[2];
 #pragma unroll
-    for (int s = 0; s < NSTEP; ++s) {
-        const int cur = s & 1;
-        if (s + 1 < NSTEP) TR_RING_FRAGS(cur ^ 1, s + 1)
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) hb[kx][hf] = hl + fa.hx[kx][hf];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) wb[hf] = wl + fa.wx[hf];
+    auto frags = [&](auto bufc, auto stepc) {
+        constexpr int BUF = decltype(bufc)::value, STEP = decltype(stepc)::value;
+        constexpr int tap_ = STEP >> 1, ky_ = tap_ / 3, kx_ = tap_ % 3, hf_ = STEP & 1;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wa[BUF][t] = *(const bf16x8*)(wb[hf_] + (tap_ * CGW + t * 32) * 64);
+#pragma unroll
+        for (int r = 0; r < R; ++r) xb[BUF][r] = *(const bf16x8*)(hb[kx_][hf_] + (r + ky_) * (HALO_W * 64));
+    };
+    frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    auto step = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int cur = s & 1;
+        if constexpr (s + 1 < NSTEP) frags(std::integral_constant<int, cur ^ 1>{}, std::integral_constant<int, s + 1>{});
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -94,9 +136,16 @@ __device__ __forceinline__ void ring_chunk_mfma(const char* hl, const char* wl, 
                 if constexpr (CT == TR_BF16) acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[cur][t], xb[cur][r], acc[r][t], 0, 0, 0);
                 else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[cur][t]), __builtin_bit_cast(f16x8, xb[cur][r]), acc[r][t], 0, 0, 0);
             }
+        if constexpr (NH > 0 && s >= 1 && (s - 1) % HS == 0 && (s - 1) / HS < NH) hook(std::integral_constant<int, HB + (s - 1) / HS>{});
         __builtin_amdgcn_sched_barrier(0);
-    }
-#undef TR_RING_FRAGS
+    };
+    static_for<NSTEP>(step);
+}
+
+template <int CT, int NT, int R>
+__device__ __forceinline__ void ring_chunk_mfma(const char* hl, const char* wl, f32x16 (&acc)[R][NT], const FragAddr& fa) {
+    auto nohook = [](auto) {};
+    ring_chunk_mfma_hooked<CT, NT, R, 0, 0>(hl, wl, acc, fa, nohook);
 }
 
 // ---- epilogue: one (row, 32-channel tile) unit of a consumer wave -----------------------------------------------------------------------
@@ -169,23 +218,26 @@ __device__ __forceinline__ void store8(const tr_view& v, int64_t pix, int co, co
     }
 }
 
-template <int CT, int SIDE, bool FAST>
-__device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& acc, const SideRaw<SIDE>& raw, char* strip, int64_t rowpix, bool rowok, int x0,
-                                                   int cobase, int l) {
+__device__ __forceinline__ void epi_write(const f32x16& acc, char* strip, int l) {
     const int lr = l & 31, lh = l >> 5;
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         *(float4*)(strip + lr * STRIP_ROW + (q * 8 + lh * 4) * 4) = make_float4(acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]);
-    // no wait between the writes and the reads below: one wave's DS instructions execute in issue order, and the compiler keeps the (possibly
-    // aliasing) write -> read order; only the read DATA is waited for
-    const int co = cobase + (l & 3) * 8;
-    float4 rd[2][2];
+}
+// no wait between the writes above and these reads: one wave's DS instructions execute in issue order, and the compiler keeps the (possibly
+// aliasing) write -> read order; only the read DATA is waited for
+__device__ __forceinline__ void epi_read(const char* strip, int l, float4 (&rd)[2][2]) {
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const int p = (l >> 2) + hf * 16;
         rd[hf][0] = *(const float4*)(strip + p * STRIP_ROW + (l & 3) * 32);
         rd[hf][1] = *(const float4*)(strip + p * STRIP_ROW + (l & 3) * 32 + 16);
     }
+}
+
+template <int CT, int SIDE, bool FAST>
+__device__ __forceinline__ void epi_finish(const ConvArgs& a, const float4 (&rd)[2][2], const SideRaw<SIDE>& raw, int64_t rowpix, bool rowok, int x0, int cobase, int l) {
+    const int co = cobase + (l & 3) * 8;
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         const int ox = x0 + (l >> 2) + hf * 16;
@@ -193,8 +245,13 @@ __device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& ac
         const bool ok = rowok && ox < a.w && co < a.cout && !(a.dbg & 4);      // dbg 4 (TRAINNER_CONV_DBG, timing experiments): no stores
         const int64_t pix = rowpix + min(ox, a.w - 1);
         if (a.act == TR_ACT_LRELU) {
+            if constexpr (FAST) {   // slope in [0, 1] (host-checked): LeakyReLU(v) = max(v, v * slope) = med3(v, v * slope, +inf): one packed multiply per pair + one med3
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= v[i] > 0.f ? 1.f : a.slope;
+                for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], v[i] * a.slope, __builtin_inff());
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] *= v[i] > 0.f ? 1.f : a.slope;
+            }
         } else if (!FAST && a.act == TR_ACT_RELU) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -246,17 +303,26 @@ __device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& ac
     }
 }
 
+template <int CT, int SIDE, bool FAST>
+__device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& acc, const SideRaw<SIDE>& raw, char* strip, int64_t rowpix, bool rowok, int x0,
+                                                   int cobase, int l) {
+    float4 rd[2][2];
+    epi_write(acc, strip, l);
+    epi_read(strip, l, rd);
+    epi_finish<CT, SIDE, FAST>(a, rd, raw, rowpix, rowok, x0, cobase, l);
+}
+
 // diagnostics: wave-uniform time stamp into a[stamps]; slot layout [workgroup][role 0 consumer / 1 loader][256 stamps]
 #define TR_STAMP(ROLE)                                                                                                  \
-    if (a.stamps && l == 0 && (ROLE == 0 ? wv == 0 : wv == NCW) && nst < 256)                                           \
+    if (a.stamps && l == 0 && (ROLE == 0 ? wv == 0 : wv == NCW) && nst < 256 && blockIdx.x < 1024)                                           \
         a.stamps[((int64_t)blockIdx.x * 2 + ROLE) * 256 + nst++] = (long long)__builtin_amdgcn_s_memtime();
 
-template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI>
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI, bool PIPE>
 __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_ring_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int SIDE = EPI % 3;          // side-input shape; EPI < 3: the fast epilogue forms (ring_epilogue_row_fast)
     constexpr bool FAST = EPI < 3;
-    typedef Cfg<NT, R, NCW, NLW, D, WRES> C;
+    typedef Cfg<NT, R, NCW, NLW, D, WRES, PIPE> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -315,8 +381,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
                         p0 = p0 < C::HALO_ITEMS - 64 ? p0 : C::HALO_ITEMS - 64;     // the tail piece re-fetches the end of the image (duplicates are benign)
                         const int P = p0 + l;
                         const int pp = P >> 2;
-                        const int s = (P & 3) ^ ((pp >> 2) & 3);                    // bank swizzle on the SOURCE: the LDS image is position-linear
                         const int py = pp / HALO_W, px = pp - py * HALO_W;
+                        const int s = (P & 3) ^ ((px >> 2) & 3);                    // bank swizzle (by the column) on the SOURCE: the LDS image is position-linear
                         int oy = y0 + py - 1 - a.shift, ox = x0 + px - 1 - a.shift;
                         bool ok = (oy >= 0) & (oy < a.ih) & (ox >= 0) & (ox < a.iw);
                         if (a.replicate) {
@@ -346,14 +412,14 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
                     }
                 }
                 if (++ch == a.nchunks) { ch = 0; ++k; }
-                if (tile_end) __builtin_amdgcn_s_barrier();      // the consumers' "stage is free for the strips" barrier of the tile that ended in iteration j - 1
+                if (!PIPE && tile_end) __builtin_amdgcn_s_barrier();      // the consumers' "stage is free for the strips" barrier of the tile that ended in iteration j - 1
                 TR_STAMP(1)
                 // chunk j - (D - 1) has landed once at most (D - 1) chunks of this wave's pieces are outstanding
                 if constexpr (D == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if constexpr (D == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NP) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * C::NP) : "memory");
             } else {
-                if (tile_end) __builtin_amdgcn_s_barrier();
+                if (!PIPE && tile_end) __builtin_amdgcn_s_barrier();
                 TR_STAMP(1)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -363,7 +429,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
             tile_end = false;
             if (j >= D - 1 && ++cch == a.nchunks) { cch = 0; tile_end = true; }
         }
-        if (tile_end) __builtin_amdgcn_s_barrier();              // the last tile's epilogue barrier
+        if (!PIPE && tile_end) __builtin_amdgcn_s_barrier();              // the last tile's epilogue barrier
         return;
     }
 
@@ -372,6 +438,100 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
     float* bias_lds = (float*)(ring + C::S * C::STAGE_BYTES);
     for (int i = tid; i < a.ncg * C::CGW; i += NCW * 64) bias_lds[i] = (a.bias && i < a.cout) ? a.bias[i] : 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // visible to the other consumer waves behind the first barrier
+    const FragAddr fa = make_frag_addr(lr, lh);
+    if constexpr (PIPE) {
+        // ---- pipelined consumers: two accumulator sets; tile k's epilogue runs as U + 1 stages hooked between the MFMA steps of tile k + 1's first
+        // EC chunks (stage H: finish unit H - 1 from the registers its strip read landed in, then park unit H in the wave's strip and read it back
+        // transposed; side inputs requested RAWN - 1 stages ahead).  A consumer wave is alone on its SIMD: VALU, LDS and store instructions
+        // issued in the shadow of its MFMAs are free, issued after them they are MFMA-pipe idle time.
+        constexpr int U = C::U, EC = C::EC;
+        constexpr int RAWN = SIDE == 2 ? 2 : 3;
+        char* strip = (char*)bias_lds + a.ncg * C::CGW * 4 + wv * STRIP_BYTES;
+        f32x16 acc[2][R][NT];
+        SideRaw<SIDE> raw[RAWN];
+        float4 rd[2][2];
+        int pcg = 0, pnb = 0, py0 = 0, px0 = 0;          // the tile whose epilogue is pending
+        bool have_prev = false;
+        for (int i = 0; i < D - 1; ++i) __builtin_amdgcn_s_barrier();
+        int c = 0;                                       // chunk counter of this workgroup (ring stage = c % S)
+        auto run_tile = [&](auto pc, int k) {
+            constexpr int P = decltype(pc)::value;
+            TR_RING_DECODE(k, cg, nb, y0, x0)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b4 = *(const float4*)(bias_lds + cg * C::CGW + t * 32 + q * 8 + lh * 4);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        acc[P][r][t][q * 4 + 0] = b4.x; acc[P][r][t][q * 4 + 1] = b4.y; acc[P][r][t][q * 4 + 2] = b4.z; acc[P][r][t][q * 4 + 3] = b4.w;
+                    }
+                }
+            auto hook = [&](auto hc) {
+                constexpr int H = decltype(hc)::value;
+                const int64_t rowbase = (int64_t)pnb * a.h;
+                if constexpr (H >= 1) {
+                    constexpr int u = H - 1, r = u / NT, t = u % NT;
+                    const int oy = py0 + wv * R + r;
+                    epi_finish<CT, SIDE, FAST>(a, rd, raw[u % RAWN], (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, px0, pcg * C::CGW + t * 32, l);
+                }
+                if constexpr (H < U) {
+                    constexpr int r = H / NT, t = H % NT;
+                    epi_write(acc[1 - P][r][t], strip, l);
+                    epi_read(strip, l, rd);
+                    if constexpr (SIDE != 0 && H + RAWN - 1 < U) {
+                        constexpr int u2 = H + RAWN - 1, r2 = u2 / NT, t2 = u2 % NT;
+                        side_issue<SIDE>(a, raw[u2 % RAWN], (rowbase + min(py0 + wv * R + r2, a.h - 1)) * a.w, px0, pcg * C::CGW + t2 * 32, l);
+                    }
+                }
+            };
+            for (int ch = 0; ch < a.nchunks; ++ch, ++c) {
+                TR_STAMP(0)
+                __builtin_amdgcn_s_barrier();
+                TR_STAMP(0)
+                const char* st = ring + (c % C::S) * C::STAGE_BYTES;
+                const char* wl = WRES ? smem + ch * C::W_BYTES : st + C::HALO_BYTES;
+                if (SIDE != 0 && ch + 1 == a.nchunks) {   // this tile's first side pieces (nchunks > EC: the previous tile's epilogue no longer holds `raw`)
+#pragma unroll
+                    for (int u = 0; u < RAWN - 1 && u < U; ++u)
+                        side_issue<SIDE>(a, raw[u], ((int64_t)nb * a.h + min(y0 + wv * R + u / NT, a.h - 1)) * a.w, x0, cg * C::CGW + (u % NT) * 32, l);
+                }
+                if (have_prev && ch == 0) ring_chunk_mfma_hooked<CT, NT, R, 0, (U + 1 < 5 ? U + 1 : 5)>(st + wv * R * (HALO_W * 64), wl, acc[P], fa, hook);
+                else if (EC > 1 && have_prev && ch == 1) ring_chunk_mfma_hooked<CT, NT, R, 5, (U + 1 > 5 ? U + 1 - 5 : 0)>(st + wv * R * (HALO_W * 64), wl, acc[P], fa, hook);
+                else ring_chunk_mfma<CT, NT, R>(st + wv * R * (HALO_W * 64), wl, acc[P], fa);
+                TR_STAMP(0)
+            }
+            pcg = cg; pnb = nb; py0 = y0; px0 = x0;
+            have_prev = true;
+            // the last tile of the workgroup: its epilogue has no MFMAs to hide behind
+            if (k + 1 == nmine) {
+                auto tail = [&](auto hc) {
+                    constexpr int H = decltype(hc)::value;
+                    const int64_t rowbase = (int64_t)pnb * a.h;
+                    if constexpr (H >= 1) {
+                        constexpr int u = H - 1, r = u / NT, t = u % NT;
+                        const int oy = py0 + wv * R + r;
+                        epi_finish<CT, SIDE, FAST>(a, rd, raw[u % RAWN], (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, px0, pcg * C::CGW + t * 32, l);
+                    }
+                    if constexpr (H < U) {
+                        constexpr int r = H / NT, t = H % NT;
+                        epi_write(acc[P][r][t], strip, l);
+                        epi_read(strip, l, rd);
+                        if constexpr (SIDE != 0 && H + RAWN - 1 < U) {
+                            constexpr int u2 = H + RAWN - 1, r2 = u2 / NT, t2 = u2 % NT;
+                            side_issue<SIDE>(a, raw[u2 % RAWN], (rowbase + min(py0 + wv * R + r2, a.h - 1)) * a.w, px0, pcg * C::CGW + t2 * 32, l);
+                        }
+                    }
+                };
+                static_for<U + 1>(tail);
+            }
+        };
+        for (int k = 0; k < nmine; k += 2) {
+            run_tile(std::integral_constant<int, 0>{}, k);
+            if (k + 1 < nmine) run_tile(std::integral_constant<int, 1>{}, k + 1);
+        }
+        return;
+    }
     f32x16 acc[R][NT];
     SideRaw<SIDE> raw[2];
     int k = 0, ch = 0;
@@ -402,7 +562,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
         // pixel of this lane in row r of the wave (clamped to the image: loads stay in range, stores are masked by `ok`)
         const int64_t rowbase = (int64_t)nb * a.h;
         if (SIDE != 0 && last) side_issue<SIDE>(a, raw[0], (rowbase + min(y0 + wv * R, a.h - 1)) * a.w, x0, cg * C::CGW, l);
-        ring_chunk_mfma<CT, NT, R>(st, wl, acc, wv * R, lr, lh);
+        ring_chunk_mfma<CT, NT, R>(st + wv * R * (HALO_W * 64), wl, acc, fa);
         TR_STAMP(0)
         if (last) {
             ch = 0;
@@ -431,14 +591,15 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
 #endif
 }
 
-template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI>
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, bool PIPE, int EPI>
 int launch_ring_side(hipStream_t st, const ConvArgs& a) {
-    typedef Cfg<NT, R, NCW, NLW, D, WRES> C;
-    const size_t lds = (size_t)C::S * C::STAGE_BYTES + (WRES ? (size_t)a.nchunks * C::W_BYTES : 0) + (size_t)a.ncg * C::CGW * 4;   // ring + resident weights + bias
+    typedef Cfg<NT, R, NCW, NLW, D, WRES, PIPE> C;
+    if (PIPE && a.nchunks <= C::EC) return -1;             // the previous tile's epilogue must be over before a tile's last chunk
+    const size_t lds = (size_t)C::S * C::STAGE_BYTES + (WRES ? (size_t)a.nchunks * C::W_BYTES : 0) + (size_t)a.ncg * C::CGW * 4 + C::STRIPS_BYTES;   // ring + resident weights + bias (+ strips)
     if (lds > (size_t)(LDS_MAX / WGS)) return -1;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        hipFuncSetAttribute((const void*)conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr_set = true;
     }
     static int ncu = 0;
@@ -450,19 +611,19 @@ int launch_ring_side(hipStream_t st, const ConvArgs& a) {
     }
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * a.ncg;
     const unsigned grid = (unsigned)(ntiles < (int64_t)ncu * WGS ? ntiles : (int64_t)ncu * WGS);
-    hipLaunchKernelGGL((conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI>), dim3(grid), dim3(C::NTHREADS), lds, st, a);
+    hipLaunchKernelGGL((conv_ring_kernel<CT, NT, R, NCW, NLW, WGS, D, WRES, EPI, PIPE>), dim3(grid), dim3(C::NTHREADS), lds, st, a);
     return tr::launch_status("tr_conv3x3(ring)");
 }
 
-template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES>
+template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, bool PIPE>
 int launch_ring(hipStream_t st, const ConvArgs& a, int epi) {
     switch (epi) {
-        case 0: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 0>(st, a);
-        case 1: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 1>(st, a);
-        case 2: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 2>(st, a);
-        case 3: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 3>(st, a);
-        case 4: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 4>(st, a);
-        default: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, 5>(st, a);
+        case 0: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 0>(st, a);
+        case 1: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 1>(st, a);
+        case 2: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 2>(st, a);
+        case 3: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 3>(st, a);
+        case 4: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 4>(st, a);
+        default: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 5>(st, a);
     }
 }
 
@@ -507,30 +668,38 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     const int64_t npix = (int64_t)a.n * a.h * a.w;
     if (!force && npix < 256 * 512) return -1;                       // fewer than ~one 16 x 32 tile per CU: the register-staged kernel's smaller tiles fill the chip better
     a.ntx = (a.w + TW - 1) / TW;
-#define TR_RING_LAUNCH(NT, R, NCW, NLW, WGS, D, WRES)                                                                   \
+#define TR_RING_LAUNCH(NT, R, NCW, NLW, WGS, D, WRES, PIPE)                                                             \
     {                                                                                                                   \
         a.nty = (a.h + (R) * (NCW) - 1) / ((R) * (NCW));                                                                 \
-        const int rc = bf ? launch_ring<TR_BF16, NT, R, NCW, NLW, WGS, D, WRES>(st, a, epi) : launch_ring<TR_F16, NT, R, NCW, NLW, WGS, D, WRES>(st, a, epi); \
+        const int rc = TR_RING_DISPATCH_CT(NT, R, NCW, NLW, WGS, D, WRES, PIPE);                                         \
         if (rc != -1) return rc;                                                                                        \
     }
-    // cfg (TRAINNER_RING_CFG, A/B experiments).  32-wide groups: 10 / 11 / 13 resident weights (16-row D 2, 16-row D 1, 8-row D 2), 0 streamed
-    // weights 16-row, 20 two workgroups per CU (8-row tiles, 2 loader waves, streamed weights).  64-wide groups: 0 16-row, 1 8-row, 2 eight consumers.
+#ifdef TR_RING_DEV   /* development builds (TRAINNER_DEV_BUILD=1): bf16 instances only, a third of the compile time */
+#define TR_RING_DISPATCH_CT(NT, R, NCW, NLW, WGS, D, WRES, PIPE) (bf ? launch_ring<TR_BF16, NT, R, NCW, NLW, WGS, D, WRES, PIPE>(st, a, epi) : -1)
+#else
+#define TR_RING_DISPATCH_CT(NT, R, NCW, NLW, WGS, D, WRES, PIPE)                                                        \
+    (bf ? launch_ring<TR_BF16, NT, R, NCW, NLW, WGS, D, WRES, PIPE>(st, a, epi) : launch_ring<TR_F16, NT, R, NCW, NLW, WGS, D, WRES, PIPE>(st, a, epi))
+#endif
+    // Instances (measured per shape on MI355X, tools/ab_ring.py; TRAINNER_RING_CFG overrides for A/B runs):
+    //   32-wide output groups, cin <= 128: resident weights, 8-row tiles, pipelined epilogue, as many ring stages as LDS holds (cfg 33 -> D 3, 2, 1);
+    //   32-wide, cin >= 160 (or cfg 0): streamed weights, 16-row tiles;
+    //   64-wide groups: streamed weights; 16-row tiles without side inputs (cfg 0), 8-row tiles with them (cfg 1: the side pieces of a whole
+    //   tile fit the registers next to the accumulators).
     if (g.cgw == 32) {
-        const int cfg = cfg_env >= 0 ? cfg_env : 10;
-        if (cfg == 20) TR_RING_LAUNCH(1, 2, 4, 2, 2, 1, false)
-        if (g.ncg == 1 && cfg >= 10) {
-            if (cfg == 10) TR_RING_LAUNCH(1, 4, 4, 4, 1, 2, true)
-            if (cfg == 10 || cfg == 11) TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, true)
-            TR_RING_LAUNCH(1, 2, 4, 4, 1, 2, true)
+        const int cfg = cfg_env >= 0 ? cfg_env : (d->cin <= 128 ? 33 : 0);
+        if (g.ncg == 1 && cfg >= 30) {
+            if (cfg == 33) TR_RING_LAUNCH(1, 2, 4, 4, 1, 3, true, true)
+            TR_RING_LAUNCH(1, 2, 4, 4, 1, 2, true, true)
+            TR_RING_LAUNCH(1, 2, 4, 4, 1, 1, true, true)
         }
-        TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false)
+        TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false, false)
     } else {
-        const int cfg = cfg_env >= 0 ? cfg_env % 10 : 0;
-        if (cfg == 1) TR_RING_LAUNCH(2, 2, 4, 4, 1, 1, false)
-        if (cfg == 2) TR_RING_LAUNCH(2, 2, 8, 4, 1, 1, false)
-        TR_RING_LAUNCH(2, 4, 4, 4, 1, 1, false)
+        const int cfg = cfg_env >= 0 ? cfg_env % 10 : (side == 0 ? 0 : 1);
+        if (cfg == 1) TR_RING_LAUNCH(2, 2, 4, 4, 1, 1, false, false)
+        TR_RING_LAUNCH(2, 4, 4, 4, 1, 1, false, false)
     }
 #undef TR_RING_LAUNCH
+#undef TR_RING_DISPATCH_CT
     return -1;
 }
 
