@@ -54,7 +54,7 @@ def check():
                 bufs = mk_bufs(n, h, w, cin, cout, dt, cd, up)
                 for form in ("plain", "lrelu", "mask", "res1", "res2"):
                     ref, ref2, _ = run("reg", None, n, h, w, cin, cout, form, dt, cd, up, bufs)
-                    for cfg in ([33, 34, 0] if cout <= 32 else [0, 1]):
+                    for cfg in ([33, 0] if cout <= 32 else [0]):
                         o, o2, _ = run("ring", cfg, n, h, w, cin, cout, form, dt, cd, up, bufs)
                         # the ring kernel seeds its accumulators with the bias (the register-staged kernel adds it after the K loop) and the compiler
                         # contracts the residual FMAs differently: fp32 results agree to a few ulps, 16-bit results to one ulp on a small fraction
@@ -81,7 +81,7 @@ def bench():
         for form in forms:
             if form == "res1" and cout == 32: continue
             line = f"n{n} {h}x{w} {cin:3d}->{cout} {form:5s}:"
-            for impl, cfg in [("reg", None)] + [("ring", c) for c in ([33, 34, 0] if cout <= 32 else [0, 1])]:
+            for impl, cfg in [("reg", None)] + [("ring", c) for c in ([33, 0] if cout <= 32 else [0])]:
                 _, _, f = run(impl, cfg, n, h, w, cin, cout, form, bufs=bufs)
                 for _ in range(2): f()
                 torch.cuda.synchronize()

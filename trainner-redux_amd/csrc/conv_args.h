@@ -17,6 +17,7 @@ struct ConvArgs {
     const float* bias;
     int ntx, nty, nchunks, ncg;
     int vec_out, vec_out2, vec_res1, vec_res2, vec_mask;
+    int ring_mb;         // conv_ring.hip, pipelined mask instances: number of LDS mask-tile buffers (1 or 2)
     long long* stamps;   // diagnostics only (TRAINNER_RING_STAMPS = device address): s_memtime stamps of workgroup phases, conv_ring.hip
     int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores, 8 = row-at-a-time epilogue
 };

@@ -57,6 +57,7 @@ struct Cfg {
     static constexpr int NSTRIP = (NCW * 2 * (32 * (32 * 4 + 16)) <= STAGE_BYTES) ? 2 : 1;   // epilogue strips per consumer wave inside one (consumed) stage
     static_assert(PIPE || NCW * NSTRIP * (32 * (32 * 4 + 16)) <= STAGE_BYTES, "the epilogue strips alias one ring stage");
     static constexpr int STRIPS_BYTES = PIPE ? NCW * (32 * (32 * 4 + 16)) : 0;               // pipelined kernels: one strip per consumer wave, LDS of its own
+    static constexpr int MASK_BYTES = PIPE ? R * NCW * 32 * 64 : 0;                          // pipelined SIDE 1: one tile of 16-bit mask values [row][32 pixels][32 channels]
     static constexpr int U = R * NT;                                                         // epilogue units per wave and tile
     static constexpr int EC = (U + 1 + 4) / 5;                                               // chunks of the NEXT tile the U + 1 epilogue stages are spread over (<= 5 hook slots per chunk)
     static_assert(HALO_ITEMS % 4 == 0 && HALO_ITEMS >= 64 && W_ITEMS % 64 == 0, "piece geometry");
@@ -303,6 +304,140 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const float4 (&rd)
     }
 }
 
+// ---- fast epilogue forms: straight-line code on buffer resources ---------------------------------------------------------------------------
+// The per-tile context holds image-based buffer resources and, per lane, the byte offset of its (column, 8-channel piece) inside a pixel row
+// -- an out-of-range offset where the column or the channels lie outside, so stores to them are dropped and loads return zeros by the
+// buffer bounds check instead of by an exec-masked branch.  A unit then adds ONE scalar offset (row, 32-channel tile) per view.  No
+// branches: the stages of the previous tile's epilogue sit in one basic block with the MFMAs of the chunk they are hooked into, and the
+// scheduler may spread them over the MFMA gaps (ring_chunk_mfma_hooked).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int SIDE>
+struct EpiTile {
+    __amdgpu_buffer_rsrc_t r_out, r_out2, r_s1, r_s2;
+    int c_out[2], c_out2[2], c_s1[2], c_s2[2];
+    int y0, cs_out, cs_out2, cs_s1, cs_s2;      // first row of the tile; row pitches are w * cstride * esize (bytes)
+    float slope, scale2, rs2;                   // act none: slope 1 ; no res2: v * 1 + 0 * res1
+};
+
+template <int CT, int SIDE>
+__device__ __forceinline__ void epi_tile_setup(const ConvArgs& a, EpiTile<SIDE>& T, int nb, int y0, int x0, int cgbase, int l) {
+    constexpr int ES_OUT = SIDE == 2 ? 4 : 2;
+    auto mk = [&](const tr_view& v, int es) {
+        const int64_t img = (int64_t)a.h * a.w * v.cstride * es;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)v.ptr + (int64_t)nb * img), 0, (unsigned)img, 0x00020000);
+    };
+    T.r_out = mk(a.out, ES_OUT);
+    T.r_out2 = (SIDE == 2 && a.out2.ptr) ? mk(a.out2, 2) : T.r_out;
+    if constexpr (SIDE == 1) T.r_s1 = mk(a.mask, 2);
+    if constexpr (SIDE == 2) {
+        T.r_s1 = mk(a.res1, 4);
+        T.r_s2 = a.res2.ptr ? mk(a.res2, 4) : T.r_s1;
+    }
+    const tr_view& s2v = (SIDE == 2 && a.res2.ptr) ? a.res2 : a.res1;
+    T.y0 = y0;
+    T.cs_out = a.w * a.out.cstride * ES_OUT;
+    T.cs_out2 = (SIDE == 2 && a.out2.ptr) ? a.w * a.out2.cstride * 2 : 0;
+    T.cs_s1 = SIDE == 1 ? a.w * a.mask.cstride * 2 : SIDE == 2 ? a.w * a.res1.cstride * 4 : 0;
+    T.cs_s2 = SIDE == 2 ? a.w * s2v.cstride * 4 : 0;
+    T.slope = a.act == TR_ACT_LRELU ? a.slope : 1.f;
+    T.scale2 = (SIDE == 2 && a.res2.ptr) ? a.scale2 : 1.f;
+    T.rs2 = (SIDE == 2 && a.res2.ptr) ? a.rs2 : 0.f;
+    const int co = cgbase + (l & 3) * 8;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int ox = x0 + (l >> 2) + hf * 16;
+        const bool ok = ox < a.w && co < a.cout;
+        const int oxc = min(ox, a.w - 1), coc = min(co, a.cout - 8);
+        T.c_out[hf] = ok ? (ox * a.out.cstride + a.out.coff + co) * ES_OUT : (int)OOB;
+        T.c_out2[hf] = (SIDE == 2 && a.out2.ptr && ok) ? (ox * a.out2.cstride + a.out2.coff + co) * 2 : (int)OOB;
+        if constexpr (SIDE == 1) T.c_s1[hf] = (oxc * a.mask.cstride + a.mask.coff + coc) * 2;
+        if constexpr (SIDE == 2) {
+            T.c_s1[hf] = (oxc * a.res1.cstride + a.res1.coff + coc) * 4;
+            T.c_s2[hf] = (oxc * s2v.cstride + s2v.coff + coc) * 4;
+        }
+    }
+}
+
+// side pieces of unit (row r of the wave, tile t) -> raw; rows past the image read the last row (their stores are dropped)
+template <int SIDE>
+__device__ __forceinline__ void side_issue_fast(const EpiTile<SIDE>& T, SideRaw<SIDE>& raw, int oyc, int t) {
+    if constexpr (SIDE == 1) {
+        const int so = oyc * T.cs_s1 + t * 64;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(T.r_s1, T.c_s1[hf], so, 0);
+            raw.q[hf] = make_uint4(q.x, q.y, q.z, q.w);
+        }
+    } else if constexpr (SIDE == 2) {
+        const int so1 = oyc * T.cs_s1 + t * 128, so2 = oyc * T.cs_s2 + t * 128;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(T.r_s1, T.c_s1[hf], so1, 0);
+            const u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(T.r_s1, T.c_s1[hf] + 16, so1, 0);
+            const u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(T.r_s2, T.c_s2[hf], so2, 0);
+            const u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(T.r_s2, T.c_s2[hf] + 16, so2, 0);
+            raw.q[hf * 4] = make_uint4(q0.x, q0.y, q0.z, q0.w);
+            raw.q[hf * 4 + 1] = make_uint4(q1.x, q1.y, q1.z, q1.w);
+            raw.q[hf * 4 + 2] = make_uint4(q2.x, q2.y, q2.z, q2.w);
+            raw.q[hf * 4 + 3] = make_uint4(q3.x, q3.y, q3.z, q3.w);
+        }
+    }
+}
+
+template <int CT, int SIDE>
+__device__ __forceinline__ void epi_finish_fast(const ConvArgs& a, const EpiTile<SIDE>& T, const float4 (&rd)[2][2], const SideRaw<SIDE>& raw, int oy, int t) {
+    const bool rowok = oy < a.h;
+    const int oyc = min(oy, a.h - 1);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        float v[8] = {rd[hf][0].x, rd[hf][0].y, rd[hf][0].z, rd[hf][0].w, rd[hf][1].x, rd[hf][1].y, rd[hf][1].z, rd[hf][1].w};
+        if constexpr (SIDE != 2) {   // LeakyReLU with slope in [0, 1] = max(v, v * slope) = med3(v, v * slope, +inf); act none: slope 1
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], v[i] * T.slope, __builtin_inff());
+        }
+        if constexpr (SIDE == 2) {
+            const uint4 qa = raw.q[hf * 4], qb = raw.q[hf * 4 + 1], qc = raw.q[hf * 4 + 2], qd = raw.q[hf * 4 + 3];
+            const float r1[8] = {__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w),
+                                 __uint_as_float(qb.x), __uint_as_float(qb.y), __uint_as_float(qb.z), __uint_as_float(qb.w)};
+            const float r2[8] = {__uint_as_float(qc.x), __uint_as_float(qc.y), __uint_as_float(qc.z), __uint_as_float(qc.w),
+                                 __uint_as_float(qd.x), __uint_as_float(qd.y), __uint_as_float(qd.z), __uint_as_float(qd.w)};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = v[i] * a.scale1 + a.rs1 * r1[i];
+                v[i] = v[i] * T.scale2 + T.rs2 * r2[i];
+            }
+        }
+        if constexpr (SIDE == 1) {
+            const uint4 q = raw.q[hf];
+            const unsigned u[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // m > 0 on the raw 16-bit patterns (bf16 and fp16 alike; activations are finite): sign clear and magnitude non-zero = a positive integer
+                v[2 * k] *= (int)(u[k] << 16) > 0 ? 1.f : a.mask_slope;
+                v[2 * k + 1] *= (int)u[k] > 0xffff ? 1.f : a.mask_slope;
+            }
+        }
+        // The (row, tile) scalar goes into the VECTOR offset of the stores, not into their SGPR offset: a store of more than 8 bytes that uses an SGPR
+        // offset may have its data registers overwritten by the VALU instruction behind it (observed on gfx950: the packed multiply of the out2
+        // scaling changed one element of the fp32 `out` piece of the last lanes of each row; loads have no such exposure).  Out-of-range stays
+        // out of range: OOB + any image offset is below 2^32 and above every num_records.
+        const unsigned vo = (rowok ? (unsigned)T.c_out[hf] : OOB);
+        if constexpr (SIDE == 2) {
+            const unsigned so = (unsigned)(oyc * T.cs_out + t * 128);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, T.r_out, (int)(vo + so), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, T.r_out, (int)(vo + so + 16u), 0, 0);
+            const float sc = a.out2_scale;
+            const unsigned vo2 = (rowok ? (unsigned)T.c_out2[hf] : OOB) + (unsigned)(oyc * T.cs_out2 + t * 64);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2c<CT>(v[0] * sc, v[1] * sc), pack2c<CT>(v[2] * sc, v[3] * sc), pack2c<CT>(v[4] * sc, v[5] * sc), pack2c<CT>(v[6] * sc, v[7] * sc)},
+                                                   T.r_out2, (int)vo2, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2c<CT>(v[0], v[1]), pack2c<CT>(v[2], v[3]), pack2c<CT>(v[4], v[5]), pack2c<CT>(v[6], v[7])}, T.r_out,
+                                                   (int)(vo + (unsigned)(oyc * T.cs_out + t * 64)), 0, 0);
+        }
+    }
+}
+
 template <int CT, int SIDE, bool FAST>
 __device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& acc, const SideRaw<SIDE>& raw, char* strip, int64_t rowpix, bool rowok, int x0,
                                                    int cobase, int l) {
@@ -369,7 +504,35 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
         int k = 0, ch = 0;
         int cch = 0;          // the consumers' chunk-in-tile counter, D - 1 iterations behind: the loaders join the per-tile epilogue barrier
         bool tile_end = false;
+        // Pipelined mask instances: the activation-derivative mask of tile km goes to LDS as well (the consumers' epilogue hooks then issue no
+        // global loads at all: a load would sit on the same in-order vmcnt as their stores and as the next tile's requests).  Tile km's mask is
+        // read during the first EC chunks of tile km + 1 and its buffer is free again after that, so with MB buffers it may be issued from
+        // iteration c0(km) + EC + D - (MB - 1) * n on (n chunks per tile) and must be issued by iteration c0(km) + n; it is issued AHEAD of the
+        // iteration's chunk pieces, so the counted wait of the iteration D - 1 later covers it.
+        constexpr bool MASKDMA = PIPE && SIDE == 1;
+        constexpr int MASK_IT = MASKDMA ? (C::TH * 2) / NLW : 1;      // 1 KiB pieces per loader wave and tile (a tile row is 32 x 64 B = 2 pieces)
+        char* maskbuf = ring + C::S * C::STAGE_BYTES + a.ncg * C::CGW * 4 + C::STRIPS_BYTES;
+        int km = 0, jmn = MASKDMA ? min(max(C::EC + D - (a.ring_mb - 1) * a.nchunks, 0), a.nchunks) : 0;
+        auto issue_mask = [&]() {
+            if constexpr (MASKDMA) {
+                TR_RING_DECODE(km, cg, nb, y0, x0)
+                const int64_t img = (int64_t)a.h * a.w * a.mask.cstride * 2;
+                const auto m_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)a.mask.ptr + (int64_t)nb * img), 0, (unsigned)img, 0x00020000);
+                char* mb = maskbuf + (km % a.ring_mb) * C::MASK_BYTES;
+#pragma unroll
+                for (int i = 0; i < MASK_IT; ++i) {
+                    const int q = i * NLW + lw;
+                    const int oy = y0 + (q >> 1), ox = x0 + (q & 1) * 16 + (l >> 2), co = cg * C::CGW + (l & 3) * 8;
+                    const bool ok = (oy < a.h) & (ox < a.w) & (co < a.cout);
+                    const unsigned off = ok ? (unsigned)((((int64_t)oy * a.w + ox) * a.mask.cstride + a.mask.coff + co) * 2) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(m_rsrc, (__attribute__((address_space(3))) void*)(mb + q * 1024), 16, off, 0, 0, 0);
+                }
+                ++km;
+                jmn += a.nchunks;
+            }
+        };
         for (int j = 0; j < total + D - 1; ++j) {
+            if (MASKDMA && j == jmn && km < nmine) issue_mask();
             if (j < total) {
                 if (ch == 0) {
                     TR_RING_DECODE(k, cg, nb, y0, x0)
@@ -430,6 +593,11 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
             if (j >= D - 1 && ++cch == a.nchunks) { cch = 0; tile_end = true; }
         }
         if (!PIPE && tile_end) __builtin_amdgcn_s_barrier();              // the last tile's epilogue barrier
+        if constexpr (PIPE) {      // tail barrier of the pipelined kernels: the last tile's mask has landed before its (unhidden) epilogue
+            if (MASKDMA && km < nmine) issue_mask();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         return;
     }
 
@@ -440,17 +608,21 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // visible to the other consumer waves behind the first barrier
     const FragAddr fa = make_frag_addr(lr, lh);
     if constexpr (PIPE) {
-        // ---- pipelined consumers: two accumulator sets; tile k's epilogue runs as U + 1 stages hooked between the MFMA steps of tile k + 1's first
-        // EC chunks (stage H: finish unit H - 1 from the registers its strip read landed in, then park unit H in the wave's strip and read it back
-        // transposed; side inputs requested RAWN - 1 stages ahead).  A consumer wave is alone on its SIMD: VALU, LDS and store instructions
-        // issued in the shadow of its MFMAs are free, issued after them they are MFMA-pipe idle time.
+        // ---- pipelined consumers (fast epilogue forms with SIDE 0 / 1 only): two accumulator sets; tile k's epilogue runs as U + 1 stages hooked
+        // between the MFMA steps of tile k + 1's first EC chunks (stage H: finish unit H - 1 from the registers its strip read landed in, then park
+        // unit H in the wave's strip and read it back transposed).  The mask pieces of a whole tile are requested when the tile STARTS (a second
+        // register set, like the accumulators): a full tile of MFMAs later they are there.  A consumer wave is alone on its SIMD: VALU, LDS and
+        // store instructions issued in the shadow of its MFMAs are free, issued after them they are MFMA-pipe idle time.
+        static_assert(FAST && SIDE != 2, "pipelined instances exist for the fast forms without residual inputs");
         constexpr int U = C::U, EC = C::EC;
-        constexpr int RAWN = SIDE == 2 ? 2 : 3;
         char* strip = (char*)bias_lds + a.ncg * C::CGW * 4 + wv * STRIP_BYTES;
         f32x16 acc[2][R][NT];
-        SideRaw<SIDE> raw[RAWN];
+        SideRaw<SIDE> mraw;                              // SIDE 1: the mask pieces of the unit being finished, read from the LDS mask tile
+        const char* maskbuf = strip - wv * STRIP_BYTES + C::STRIPS_BYTES;
+        int pk = 0;                                      // tile number of the pending epilogue (mask buffer pk % MB)
         float4 rd[2][2];
-        int pcg = 0, pnb = 0, py0 = 0, px0 = 0;          // the tile whose epilogue is pending
+        int py0 = 0;                                     // first row of the tile whose epilogue is pending
+        EpiTile<SIDE> T;                                 // its buffer-resource context: built at the start of a tile's last chunk (nchunks > EC)
         bool have_prev = false;
         for (int i = 0; i < D - 1; ++i) __builtin_amdgcn_s_barrier();
         int c = 0;                                       // chunk counter of this workgroup (ring stage = c % S)
@@ -469,19 +641,18 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
                 }
             auto hook = [&](auto hc) {
                 constexpr int H = decltype(hc)::value;
-                const int64_t rowbase = (int64_t)pnb * a.h;
                 if constexpr (H >= 1) {
                     constexpr int u = H - 1, r = u / NT, t = u % NT;
-                    const int oy = py0 + wv * R + r;
-                    epi_finish<CT, SIDE, FAST>(a, rd, raw[u % RAWN], (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, px0, pcg * C::CGW + t * 32, l);
+                    epi_finish_fast<CT, SIDE>(a, T, rd, mraw, py0 + wv * R + r, t);
                 }
                 if constexpr (H < U) {
                     constexpr int r = H / NT, t = H % NT;
                     epi_write(acc[1 - P][r][t], strip, l);
                     epi_read(strip, l, rd);
-                    if constexpr (SIDE != 0 && H + RAWN - 1 < U) {
-                        constexpr int u2 = H + RAWN - 1, r2 = u2 / NT, t2 = u2 % NT;
-                        side_issue<SIDE>(a, raw[u2 % RAWN], (rowbase + min(py0 + wv * R + r2, a.h - 1)) * a.w, px0, pcg * C::CGW + t2 * 32, l);
+                    if constexpr (SIDE == 1) {
+                        const char* mb = maskbuf + (pk % a.ring_mb) * C::MASK_BYTES + ((wv * R + r) * 32 + (l >> 2)) * 64 + (l & 3) * 16;
+                        mraw.q[0] = *(const uint4*)mb;
+                        mraw.q[1] = *(const uint4*)(mb + 16 * 64);
                     }
                 }
             };
@@ -491,35 +662,35 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
                 TR_STAMP(0)
                 const char* st = ring + (c % C::S) * C::STAGE_BYTES;
                 const char* wl = WRES ? smem + ch * C::W_BYTES : st + C::HALO_BYTES;
-                if (SIDE != 0 && ch + 1 == a.nchunks) {   // this tile's first side pieces (nchunks > EC: the previous tile's epilogue no longer holds `raw`)
-#pragma unroll
-                    for (int u = 0; u < RAWN - 1 && u < U; ++u)
-                        side_issue<SIDE>(a, raw[u], ((int64_t)nb * a.h + min(y0 + wv * R + u / NT, a.h - 1)) * a.w, x0, cg * C::CGW + (u % NT) * 32, l);
-                }
                 if (have_prev && ch == 0) ring_chunk_mfma_hooked<CT, NT, R, 0, (U + 1 < 5 ? U + 1 : 5)>(st + wv * R * (HALO_W * 64), wl, acc[P], fa, hook);
                 else if (EC > 1 && have_prev && ch == 1) ring_chunk_mfma_hooked<CT, NT, R, 5, (U + 1 > 5 ? U + 1 - 5 : 0)>(st + wv * R * (HALO_W * 64), wl, acc[P], fa, hook);
                 else ring_chunk_mfma<CT, NT, R>(st + wv * R * (HALO_W * 64), wl, acc[P], fa);
                 TR_STAMP(0)
+                // nchunks > EC: the previous tile's epilogue is over, the store context passes to this tile
+                if (ch == EC - 1 || (ch == 0 && !have_prev)) {
+                    epi_tile_setup<CT, SIDE>(a, T, nb, y0, x0, cg * C::CGW, l);
+                    py0 = y0;
+                    pk = k;
+                }
             }
-            pcg = cg; pnb = nb; py0 = y0; px0 = x0;
             have_prev = true;
             // the last tile of the workgroup: its epilogue has no MFMAs to hide behind
             if (k + 1 == nmine) {
+                __builtin_amdgcn_s_barrier();                    // tail barrier: the loaders have waited for the last mask tile
                 auto tail = [&](auto hc) {
                     constexpr int H = decltype(hc)::value;
-                    const int64_t rowbase = (int64_t)pnb * a.h;
                     if constexpr (H >= 1) {
                         constexpr int u = H - 1, r = u / NT, t = u % NT;
-                        const int oy = py0 + wv * R + r;
-                        epi_finish<CT, SIDE, FAST>(a, rd, raw[u % RAWN], (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, px0, pcg * C::CGW + t * 32, l);
+                        epi_finish_fast<CT, SIDE>(a, T, rd, mraw, py0 + wv * R + r, t);
                     }
                     if constexpr (H < U) {
                         constexpr int r = H / NT, t = H % NT;
                         epi_write(acc[P][r][t], strip, l);
                         epi_read(strip, l, rd);
-                        if constexpr (SIDE != 0 && H + RAWN - 1 < U) {
-                            constexpr int u2 = H + RAWN - 1, r2 = u2 / NT, t2 = u2 % NT;
-                            side_issue<SIDE>(a, raw[u2 % RAWN], (rowbase + min(py0 + wv * R + r2, a.h - 1)) * a.w, px0, pcg * C::CGW + t2 * 32, l);
+                        if constexpr (SIDE == 1) {
+                            const char* mb = maskbuf + (pk % a.ring_mb) * C::MASK_BYTES + ((wv * R + r) * 32 + (l >> 2)) * 64 + (l & 3) * 16;
+                            mraw.q[0] = *(const uint4*)mb;
+                            mraw.q[1] = *(const uint4*)(mb + 16 * 64);
                         }
                     }
                 };
@@ -534,6 +705,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
     }
     f32x16 acc[R][NT];
     SideRaw<SIDE> raw[2];
+    EpiTile<SIDE> T;
     int k = 0, ch = 0;
     int cg = 0, nb = 0, y0 = 0, x0 = 0;
     for (int j = 0; j < total + D - 1; ++j) {
@@ -561,7 +733,12 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
         const bool last = ch + 1 == a.nchunks;
         // pixel of this lane in row r of the wave (clamped to the image: loads stay in range, stores are masked by `ok`)
         const int64_t rowbase = (int64_t)nb * a.h;
-        if (SIDE != 0 && last) side_issue<SIDE>(a, raw[0], (rowbase + min(y0 + wv * R, a.h - 1)) * a.w, x0, cg * C::CGW, l);
+        if constexpr (FAST) {
+            if (last) {
+                epi_tile_setup<CT, SIDE>(a, T, nb, y0, x0, cg * C::CGW, l);
+                if constexpr (SIDE != 0) side_issue_fast<SIDE>(T, raw[0], min(y0 + wv * R, a.h - 1), 0);
+            }
+        } else if (SIDE != 0 && last) side_issue<SIDE>(a, raw[0], (rowbase + min(y0 + wv * R, a.h - 1)) * a.w, x0, cg * C::CGW, l);
         ring_chunk_mfma<CT, NT, R>(st + wv * R * (HALO_W * 64), wl, acc, fa);
         TR_STAMP(0)
         if (last) {
@@ -576,12 +753,22 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
             for (int u = 0; u < R * NT; ++u) {
                 const int r = u / NT, t = u % NT;
                 const int oy = y0 + wv * R + r;
-                if (SIDE != 0 && u + 1 < R * NT) {
-                    const int r1 = (u + 1) / NT, t1 = (u + 1) % NT;
-                    side_issue<SIDE>(a, raw[(u + 1) & 1], (rowbase + min(y0 + wv * R + r1, a.h - 1)) * a.w, x0, cg * C::CGW + t1 * 32, l);
+                char* strip = strips + (u % C::NSTRIP) * STRIP_BYTES;
+                if constexpr (FAST) {
+                    if constexpr (SIDE != 0) {
+                        if (u + 1 < R * NT) side_issue_fast<SIDE>(T, raw[(u + 1) & 1], min(y0 + wv * R + (u + 1) / NT, a.h - 1), (u + 1) % NT);
+                    }
+                    float4 rd[2][2];
+                    epi_write(acc[r][t], strip, l);
+                    epi_read(strip, l, rd);
+                    epi_finish_fast<CT, SIDE>(a, T, rd, raw[u & 1], oy, t);
+                } else {
+                    if (SIDE != 0 && u + 1 < R * NT) {
+                        const int r1 = (u + 1) / NT, t1 = (u + 1) % NT;
+                        side_issue<SIDE>(a, raw[(u + 1) & 1], (rowbase + min(y0 + wv * R + r1, a.h - 1)) * a.w, x0, cg * C::CGW + t1 * 32, l);
+                    }
+                    ring_epilogue_unit<CT, SIDE, FAST>(a, acc[r][t], raw[u & 1], strip, (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, x0, cg * C::CGW + t * 32, l);
                 }
-                ring_epilogue_unit<CT, SIDE, FAST>(a, acc[r][t], raw[u & 1], strips + (u % C::NSTRIP) * STRIP_BYTES, (rowbase + min(oy, a.h - 1)) * a.w, oy < a.h, x0,
-                                                   cg * C::CGW + t * 32, l);
             }
         } else {
             ++ch;
@@ -592,10 +779,18 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
 }
 
 template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, bool PIPE, int EPI>
-int launch_ring_side(hipStream_t st, const ConvArgs& a) {
+int launch_ring_side(hipStream_t st, const ConvArgs& a_in) {
     typedef Cfg<NT, R, NCW, NLW, D, WRES, PIPE> C;
+    ConvArgs a = a_in;
     if (PIPE && a.nchunks <= C::EC) return -1;             // the previous tile's epilogue must be over before a tile's last chunk
-    const size_t lds = (size_t)C::S * C::STAGE_BYTES + (WRES ? (size_t)a.nchunks * C::W_BYTES : 0) + (size_t)a.ncg * C::CGW * 4 + C::STRIPS_BYTES;   // ring + resident weights + bias (+ strips)
+    a.ring_mb = 1;
+    if (PIPE && EPI == 1) {                                // LDS mask tiles: one buffer if a tile has room for "free, then refill" (n >= EC + D), else two
+        static_assert(!(PIPE && EPI == 1) || NT == 1, "the LDS mask tile is one 32-channel group wide");
+        a.ring_mb = a.nchunks >= C::EC + D ? 1 : 2;
+        if (C::EC + D > a.ring_mb * a.nchunks) return -1;
+    }
+    const size_t lds = (size_t)C::S * C::STAGE_BYTES + (WRES ? (size_t)a.nchunks * C::W_BYTES : 0) + (size_t)a.ncg * C::CGW * 4 + C::STRIPS_BYTES +
+                       ((PIPE && EPI == 1) ? (size_t)a.ring_mb * C::MASK_BYTES : 0);   // ring + resident weights + bias (+ strips, + mask tiles)
     if (lds > (size_t)(LDS_MAX / WGS)) return -1;
     static bool attr_set = false;
     if (!attr_set) {
@@ -617,13 +812,19 @@ int launch_ring_side(hipStream_t st, const ConvArgs& a) {
 
 template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, bool PIPE>
 int launch_ring(hipStream_t st, const ConvArgs& a, int epi) {
-    switch (epi) {
-        case 0: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 0>(st, a);
-        case 1: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 1>(st, a);
-        case 2: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 2>(st, a);
-        case 3: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 3>(st, a);
-        case 4: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 4>(st, a);
-        default: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 5>(st, a);
+    if constexpr (PIPE) {      // pipelined instances: fast forms without residual inputs
+        if (epi == 0) return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 0>(st, a);
+        if (epi == 1) return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 1>(st, a);
+        return -1;
+    } else {
+        switch (epi) {
+            case 0: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 0>(st, a);
+            case 1: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 1>(st, a);
+            case 2: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 2>(st, a);
+            case 3: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 3>(st, a);
+            case 4: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 4>(st, a);
+            default: return launch_ring_side<CT, NT, R, NCW, NLW, WGS, D, WRES, PIPE, 5>(st, a);
+        }
     }
 }
 
@@ -657,6 +858,8 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     if (side == 0) fast = lrelu_ok && d->out.dtype == ct && !d->out2.ptr;
     else if (side == 1) fast = d->act == TR_ACT_NONE && d->out.dtype == ct && d->mask.dtype == ct && !d->out2.ptr;
     else fast = d->act == TR_ACT_NONE && d->out.dtype == TR_F32 && (!d->out2.ptr || d->out2.dtype == ct);
+    auto img_ok = [&](const tr_view& v) { return !v.ptr || (int64_t)d->h * d->w * v.cstride * tr::esize(v.dtype) < (int64_t)0x7fff0000; };
+    if (d->cout % 32 != 0 || !img_ok(d->out) || !img_ok(d->out2) || !img_ok(d->res1) || !img_ok(d->res2) || !img_ok(d->mask)) fast = false;   // buffer addressing of the fast forms
     if (getenv("TRAINNER_RING_GENERIC")) fast = false;               // A/B switch
     const int epi = fast ? side : side + 3;
     if (!vec16_ok(d->out) || !vec16_ok(d->out2) || !vec16_ok(d->res1) || !vec16_ok(d->res2) || !vec16_ok(d->mask)) return -1;
@@ -683,8 +886,7 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     // Instances (measured per shape on MI355X, tools/ab_ring.py; TRAINNER_RING_CFG overrides for A/B runs):
     //   32-wide output groups, cin <= 128: resident weights, 8-row tiles, pipelined epilogue, as many ring stages as LDS holds (cfg 33 -> D 3, 2, 1);
     //   32-wide, cin >= 160 (or cfg 0): streamed weights, 16-row tiles;
-    //   64-wide groups: streamed weights; 16-row tiles without side inputs (cfg 0), 8-row tiles with them (cfg 1: the side pieces of a whole
-    //   tile fit the registers next to the accumulators).
+    //   64-wide groups: streamed weights, 16-row tiles.
     if (g.cgw == 32) {
         const int cfg = cfg_env >= 0 ? cfg_env : (d->cin <= 128 ? 33 : 0);
         if (g.ncg == 1 && cfg >= 30) {
@@ -694,8 +896,6 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
         }
         TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false, false)
     } else {
-        const int cfg = cfg_env >= 0 ? cfg_env % 10 : (side == 0 ? 0 : 1);
-        if (cfg == 1) TR_RING_LAUNCH(2, 2, 4, 4, 1, 1, false, false)
         TR_RING_LAUNCH(2, 4, 4, 4, 1, 1, false, false)
     }
 #undef TR_RING_LAUNCH
