@@ -1,0 +1,79 @@
+"""A/B of the wgrad ring kernel (wgrad_ring.hip) against the register-staged wgrad kernel: dW / db agreement on slices of dense-block shaped buffers
+(ragged sizes, nearest-2x input), then timings per shape.  Run on the GPU box."""
+import os, sys, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import trainner_redux_amd
+from trainner_redux_amd import _lib as L, ops
+
+dev = torch.device("cuda")
+torch.manual_seed(0)
+
+
+def mk(n, h, w, cin, cout, dt, up=False):
+    hi, wi = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(n, hi, wi, cin + 32, device=dev).to(dt)
+    gy = (torch.randn(n, h, w, cout + 32, device=dev) / 16).to(dt)
+    ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout) // 4 + 16, dtype=torch.float32, device=dev)
+    return x, gy, ws
+
+
+def run(impl, n, h, w, cin, cout, cd, bufs, up=False, accumulate=False):
+    os.environ["TRAINNER_WGRAD_IMPL"] = impl
+    x, gy, ws = bufs
+    dw = torch.full((cout, cin, 3, 3), 0.5, device=dev)
+    db = torch.full((cout,), 0.25, device=dev)
+    f = lambda: ops.wgrad3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=cd, inp=ops.view(x, 16, cin), gy=ops.view(gy, 8, cout), dw=dw, db=db, workspace=ws,
+                             in_mode=L.IN_NEAREST2X if up else L.IN_DIRECT, accumulate=accumulate)
+    f()
+    torch.cuda.synchronize()
+    return dw, db, f
+
+
+def check():
+    bad = 0
+    cases = [(2, 40, 70, 64, 32), (1, 16, 32, 96, 32), (3, 33, 31, 128, 32), (1, 50, 100, 160, 32), (2, 24, 64, 192, 64), (1, 17, 130, 64, 64), (1, 64, 64, 64, 48), (1, 32, 64, 72, 24)]
+    for (n, h, w, cin, cout) in cases:
+        for dt, cd in ((torch.bfloat16, L.BF16), (torch.float16, L.F16)):
+            for up in (False, True):
+                if up and (h % 2 or w % 2): continue
+                bufs = mk(n, h, w, cin, cout, dt, up)
+                for acc in (False, True):
+                    rw, rb, _ = run("reg", n, h, w, cin, cout, cd, bufs, up, acc)
+                    ow, ob, _ = run("ring", n, h, w, cin, cout, cd, bufs, up, acc)
+                    # same products, another summation order (fp32): a few 1e-6 of the gradient's scale
+                    scale = rw.abs().max().item()
+                    ew = (ow - rw).abs().max().item() / scale
+                    eb = (ob - rb).abs().max().item() / max(rb.abs().max().item(), 1e-6)
+                    if not (ew < 2e-5 and eb < 2e-5):
+                        bad += 1
+                        print(f"MISMATCH n{n} {h}x{w} {cin}->{cout} {dt} up{int(up)} acc{int(acc)}: dw {ew:.2e} db {eb:.2e}")
+    print("check done, mismatches:", bad)
+    return bad
+
+
+def bench():
+    shapes = [(16, 256, 256, 64, 32), (16, 256, 256, 96, 32), (16, 256, 256, 128, 32), (16, 256, 256, 160, 32), (16, 256, 256, 192, 64),
+              (16, 1024, 1024, 64, 64), (16, 512, 512, 64, 64)]
+    for (n, h, w, cin, cout) in shapes:
+        bufs = mk(n, h, w, cin, cout, torch.bfloat16)
+        flops = 2.0 * n * h * w * 9 * cin * cout
+        line = f"n{n} {h}x{w} {cin:3d}->{cout}:"
+        for impl in ("reg", "ring"):
+            _, _, f = run(impl, n, h, w, cin, cout, L.BF16, bufs)
+            for _ in range(2): f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): f()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            line += f"  {impl} {ms:6.3f}ms {flops / ms / 1e9:6.0f}TF"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "check"
+    if what in ("check", "all"):
+        if check() and what == "all": sys.exit(1)
+    if what in ("bench", "all"): bench()

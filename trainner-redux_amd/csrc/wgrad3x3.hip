@@ -15,6 +15,7 @@
 //   * partials go to a caller workspace and a second kernel sums them in fixed slot order:
 //     bitwise reproducible, no float atomics.
 #include "common.h"
+#include "wgrad_args.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -31,16 +32,6 @@ constexpr int TW = 32, TH = 8;
 constexpr int NTHREADS = 192;
 constexpr int CKW = 32;   // input channels per workgroup
 
-struct WgArgs {
-    int n, h, w, hin, win;
-    int ih, iw, shift;   // input extent in output coordinates and its origin shift (TR_IN_FULL: +1, TR_IN_VALID: -1)
-    int cin, cout;
-    int up, replicate;
-    tr_view in, gy;
-    float* partials;
-    float* db_partials;   // [slot][ncg][CG] or null
-    int ntx, nty, ntiles, nslots, nchunks, ncg;
-};
 
 template <int CT, int NT, int KS>
 __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void wgrad_kernel(WgArgs a) {
@@ -532,12 +523,18 @@ int launch_wgrad(hipStream_t st, const WgArgs& a) {
 extern "C" size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     const Plan p = make_plan(n, h, w, cin, cout);
-    return (p.dw_floats + p.db_floats) * sizeof(float);
+    const tr::WgRingPlan r = tr::wgrad_ring_plan(n, h, w, cin, cout);
+    const size_t a = p.dw_floats + p.db_floats, b = r.dw_floats + r.db_floats;
+    return (a > b ? a : b) * sizeof(float);
 }
 extern "C" size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return 0;
     const Plan p = make_plan(n, h, w, cin, cout, ksize);
     size_t fl = p.dw_floats + p.db_floats;
+    if (ksize == 3) {
+        const tr::WgRingPlan r = tr::wgrad_ring_plan(n, h, w, cin, cout);
+        if (r.dw_floats + r.db_floats > fl) fl = r.dw_floats + r.db_floats;
+    }
     if (ksize == 1 && cout > 32) {     // the split-K GEMM path (16-bit compute, direct input) keeps 128 x 192 blocks per workgroup
         const LwPlan q = lw_plan((int64_t)n * h * w, cin, cout);
         if (q.dw_floats + q.db_floats > fl) fl = q.dw_floats + q.db_floats;
@@ -609,6 +606,21 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     a.ntx = p.ntx; a.nty = p.nty; a.ntiles = p.ntiles; a.nslots = p.nslots; a.nchunks = p.nchunks; a.ncg = p.ncg;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    {   // the persistent LDS-DMA ring kernel (wgrad_ring.hip) takes the large 16-bit 3x3 launches; same partial layout, same reduction
+        WgArgs ar = a;
+        tr::WgRingPlan rp;
+        rc = tr::wgrad3x3_ring(st, d, ar, rp);
+        if (rc > 0) return rc;
+        if (rc == 0) {
+            const int64_t total = (int64_t)d->cout * 9 * d->cin;
+            int64_t b = (total + 63) / 64;
+            if (b > 8192) b = 8192;
+            const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, rp.slots_eff, rp.nchunks,
+                               rp.ncg, rp.cgw, d->accumulate, 9, (int)b, d->partials + rp.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
+            return tr::launch_status("tr_wgrad3x3(ring reduce)");
+        }
+    }
     if (d->ksize == 1) {
         if (d->compute == TR_BF16) rc = p.cgw == 64 ? launch_wgrad<TR_BF16, 2, 1>(st, a) : launch_wgrad<TR_BF16, 1, 1>(st, a);
         else if (d->compute == TR_F16) rc = p.cgw == 64 ? launch_wgrad<TR_F16, 2, 1>(st, a) : launch_wgrad<TR_F16, 1, 1>(st, a);
