@@ -122,6 +122,12 @@ int    tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d);
 int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_oihw, int cout, int cin, int n, int h, int w, int pad_mode,
                            const float* ch_scale_host, float* dst_nchw, int accumulate);
 
+/* Stem convolution straight from the NCHW fp32 image (the DataFeed contract, utils/types.py:10-17): (x - mean[c]) / std[c]
+ * (perceptual_fp16_loss.py:322; host pointers, may be NULL), zero or replicate padding (:272-274), 3x3 conv with cin <= 3 input channels,
+ * bias, optional ReLU -> NHWC fp32 view of cout channels.  VGG19 conv1_1 of the perceptual head.  Weights / bias: fp32 OIHW master tensors. */
+int tr_conv3x3_stem(void* stream, const float* src_nchw, const float* w_oihw, const float* bias, const float* mean_host, const float* std_host,
+                    int cin, int cout, int n, int h, int w, int pad_mode, int act, tr_view out);
+
 /* Adjoint of F.pad(mode="replicate", pad=1) + NHWC->NCHW + per-channel scale, for the stem of the perceptual head
  * (perceptual_fp16_loss.py:272-274,322): gp is the gradient w.r.t. the PADDED image, NHWC n x (h+2) x (w+2);
  * dst[n,c,y,x] (+)= ch_scale[c] * sum of gp over every padded position that replicate-padding filled from (y,x). */

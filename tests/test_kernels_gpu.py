@@ -372,6 +372,31 @@ def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
     assert rel_l2(out2.cpu(), img.grad) < 3e-6
 
 
+@pytest.mark.parametrize("pad", ["replicate", "zeros"])
+@pytest.mark.parametrize("shape", [(2, 14, 38, 64, True), (1, 9, 7, 64, False), (1, 33, 20, 24, True), (1, 8, 16, 128, True)])
+def test_stem_conv_from_nchw_image(cuda, pad, shape):
+    """tr_conv3x3_stem (VGG19 conv1_1, perceptual_fp16_loss.py:272-274,322): normalise + pad + 3x3 conv + bias + ReLU straight from the NCHW
+    image into a channel slice of an NHWC buffer, against torch in fp32 (fp32 FMA chains in another order: 1e-6)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cout, relu = shape
+    g = torch.Generator().manual_seed(17)
+    img = torch.rand(n, 3, h, w, generator=g)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) / 5
+    b = torch.randn(cout, generator=g)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    xin = (img - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    ref = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="replicate" if pad == "replicate" else "constant"), wt, b)
+    if relu:
+        ref = ref.relu()
+    buf = torch.full((n, h, w, cout + 8), 7.0, device=cuda)
+    ops.conv3x3_stem(img.to(cuda), wt.to(cuda), b.to(cuda), ops.view(buf, 4, cout), mean=mean, std=std,
+                     pad_mode=L.PAD_REPLICATE if pad == "replicate" else L.PAD_ZEROS, act=L.ACT_RELU if relu else L.ACT_NONE)
+    got = buf[..., 4:4 + cout].permute(0, 3, 1, 2).cpu()
+    assert rel_l2(got, ref) < 2e-6
+    assert torch.all(buf[..., :4] == 7.0) and torch.all(buf[..., 4 + cout:] == 7.0)      # the slice's neighbours are untouched
+
+
 @pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180), (2, 18, 32, 192, 540), (1, 8, 32, 192, 256),
                                   (1, 6, 32, 192, 300), (2, 16, 32, 192, 360), (1, 9, 32, 64, 120), (1, 8, 48, 64, 60), (2, 5, 32, 64, 24)])

@@ -110,6 +110,8 @@ SYMBOLS = {
     "tr_conv3x3_winograd_f32": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
     "tr_conv3x3_dgrad_image": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_int]),
+    "tr_conv3x3_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, View]),
     "tr_fold_replicate_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),
     "tr_pack_conv3x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64]),
     "tr_wgrad3x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -87,6 +87,78 @@ __global__ __launch_bounds__(256) void fold_replicate_kernel(tr_view gp, float* 
     }
 }
 
+
+// ---- stem convolution of an NCHW fp32 image: normalise, pad, 3x3 conv (<= 4 -> cout channels), bias, ReLU -> NHWC fp32 view ------------------
+// VGG19 conv1_1 (perceptual_fp16_loss.py:272-274,322): K = 27 is far too narrow for MFMA and the layer is bound by its output (256 B per pixel
+// against 12 B of input), so this is a VALU kernel whose only job is to write full pixel records: 16 lanes per pixel, 4 output channels each
+// (their 27 x 4 weights live in registers), one 16-byte store per lane = 256 contiguous bytes per pixel.  Replaces tr_nchw_to_nhwc + the
+// generic fp32 MFMA conv (3.3 ms per launch at batch 16, 1024^2: 29 of its 32 K-lanes multiply zeros).
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias, float4 mean,
+                                                         float4 istd, int cin, int cout, int n, int h, int wd, int replicate, int relu, tr_view out, int ntx,
+                                                         int nty) {
+    // workgroup = one 8 x 32 pixel tile: its normalised, padded 10 x 34 x 3 input patch goes through LDS once (coalesced plane reads), then
+    // lane (pixel p, channel quad q) walks the tile 16 pixels at a time; a first version fetched the 27 inputs of a pixel per lane from global
+    // memory and was latency bound at 3 waves per SIMD (8.5 ms, worse than the MFMA kernel it replaces)
+    __shared__ float xin[3][10][36];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int ncq = cout >> 2;
+    const float mn[4] = {mean.x, mean.y, mean.z, mean.w}, is[4] = {istd.x, istd.y, istd.z, istd.w};
+    const int64_t hw = (int64_t)h * wd;
+    const int ntiles = ntx * nty * n;
+    for (int q0 = 0; q0 < ncq; q0 += 16) {            // cout > 64: a lane takes one channel quad per sweep over the tiles
+        const int q = q0 + cq;
+        const bool qok = q < ncq;
+        float wr[3][9][4];                             // [ci][tap][co of the quad]
+        float b4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b4[j] = (bias && qok) ? bias[q * 4 + j] : 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wr[ci][t][j] = (ci < cin && qok) ? w[((int64_t)(q * 4 + j) * cin + ci) * 9 + t] : 0.f;
+        }
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            int t_ = tile;
+            const int x0 = (t_ % ntx) * 32; t_ /= ntx;
+            const int y0 = (t_ % nty) * 8;
+            const int nb = t_ / nty;
+            __syncthreads();                          // the previous tile's patch has been consumed
+            for (int i = threadIdx.x; i < 3 * 10 * 34; i += 256) {
+                const int ci = i / 340, r = (i - ci * 340) / 34, c = i - ci * 340 - r * 34;
+                const int y = y0 + r - 1, x = x0 + c - 1;
+                const bool ok = ci < cin && (replicate || (y >= 0 && y < h && x >= 0 && x < wd));
+                const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), wd - 1);
+                // zero padding pads the NORMALISED image; columns / rows past the image on partial tiles read clamped pixels (never stored)
+                xin[ci][r][c] = ok ? (src[((int64_t)nb * cin + min(ci, cin - 1)) * hw + (int64_t)yc * wd + xc] - mn[ci]) * is[ci] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int pass = 0; pass < 16; ++pass) {
+                const int p = pass * 16 + pl, ry = p >> 5, rx = p & 31;
+                float acc[4] = {b4[0], b4[1], b4[2], b4[3]};
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float v = xin[ci][ry + ky][rx + kx];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[j] += v * wr[ci][ky * 3 + kx][j];
+                        }
+                if (relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaxf(acc[j], 0.f);
+                }
+                const int oy = y0 + ry, ox = x0 + rx;
+                if (qok && oy < h && ox < wd)
+                    *(float4*)((float*)out.ptr + (((int64_t)nb * h + oy) * wd + ox) * out.cstride + out.coff + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tr_fold_replicate_nchw(void* stream, tr_view gp, float* dst_nchw, int n, int c, int h, int w, const float* ch_scale,
@@ -120,4 +192,24 @@ extern "C" int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_o
     hipLaunchKernelGGL(dgrad_image_kernel, dim3((unsigned)blocks), dim3(256), 9 * cout * MAXC * sizeof(float), (hipStream_t)stream, gy, w_oihw,
                        cout, cin, n, h, w, pad_mode == TR_PAD_REPLICATE, chs, dst_nchw, accumulate, (int)tr::view_vec4_ok(gy));
     return tr::launch_status("tr_conv3x3_dgrad_image");
+}
+
+extern "C" int tr_conv3x3_stem(void* stream, const float* src_nchw, const float* w_oihw, const float* bias, const float* mean_host, const float* std_host,
+                               int cin, int cout, int n, int h, int w, int pad_mode, int act, tr_view out) {
+    TR_REQUIRE(src_nchw && w_oihw && out.ptr && n > 0 && h > 0 && w > 0, TR_EINVAL, "tr_conv3x3_stem: bad arguments");
+    TR_REQUIRE(cin >= 1 && cin <= 3 && cout % 4 == 0 && cout > 0, TR_EUNSUPPORTED, "tr_conv3x3_stem: needs cin <= 3 and cout a multiple of 4");
+    TR_REQUIRE(out.dtype == TR_F32 && out.c >= cout && out.coff + cout <= out.cstride && tr::view_vec4_ok(out), TR_EINVAL,
+               "tr_conv3x3_stem: out must be a 16-byte sliceable fp32 view of cout channels");
+    TR_REQUIRE(act == TR_ACT_NONE || act == TR_ACT_RELU, TR_EUNSUPPORTED, "tr_conv3x3_stem: act must be none or ReLU");
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f};
+    for (int i = 0; i < cin; ++i) {
+        if (mean_host) m[i] = mean_host[i];
+        if (std_host) is[i] = 1.f / std_host[i];
+    }
+    const int ntx = (w + 31) / 32, nty = (h + 7) / 8;
+    int64_t blocks = (int64_t)ntx * nty * n;
+    if (blocks > 256 * 12) blocks = 256 * 12;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src_nchw, w_oihw, bias, make_float4(m[0], m[1], m[2], m[3]),
+                       make_float4(is[0], is[1], is[2], is[3]), cin, cout, n, h, w, pad_mode == TR_PAD_REPLICATE, act == TR_ACT_RELU, out, ntx, nty);
+    return tr::launch_status("tr_conv3x3_stem");
 }

@@ -225,7 +225,11 @@ class VGG(nn.Module):
         only the tapped features in ws['feats_gt']."""
         n, _, h, w = img.shape
         V = ops.view
-        ops.nchw_to_nhwc(img, ws["a0"], IMAGENET_MEAN, IMAGENET_STD)
+        # fp32 head: conv1_1 runs as the dedicated stem kernel straight from the NCHW image (normalisation and replicate padding fused); the 16-bit
+        # head (perceptualfp16loss) keeps the generic path: layout pass into an 8-channel NHWC buffer + MFMA conv
+        stem = ws["a0"].dtype == torch.float32 and img.dtype == torch.float32 and img.shape[1] <= 3 and not os.environ.get("TRAINNER_NO_STEM")
+        if not stem:
+            ops.nchw_to_nhwc(img, ws["a0"], IMAGENET_MEAN, IMAGENET_STD)
         cur, cur_c = ws["a0"], 8
         hh, ww = h, w
         first = True
@@ -241,9 +245,13 @@ class VGG(nn.Module):
                     out = ws["scratch"][flip].view(-1)[: n * hh * ww * m.cout].view(n, hh, ww, m.cout)
                     flip ^= 1
                 wino = len(pk[name]) > 2 and not first and hh % 2 == 0 and ww % 2 == 0
-                ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD if wino else cd, inp=V(cur, 0, cur_c), out=V(out),
-                            wpacked=pk[name][2 if wino else 0], bias=m.bias.data, act=L.ACT_RELU if fused_relu else L.ACT_NONE,
-                            pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
+                if first and stem:
+                    ops.conv3x3_stem(img.contiguous(), m.weight.data, m.bias.data, V(out), mean=IMAGENET_MEAN, std=IMAGENET_STD, pad_mode=L.PAD_REPLICATE,
+                                     act=L.ACT_RELU if fused_relu else L.ACT_NONE)
+                else:
+                    ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD if wino else cd, inp=V(cur, 0, cur_c), out=V(out),
+                                wpacked=pk[name][2 if wino else 0], bias=m.bias.data, act=L.ACT_RELU if fused_relu else L.ACT_NONE,
+                                pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
                 first = False
                 cur, cur_c = out, m.cout
             else:

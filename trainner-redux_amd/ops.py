@@ -195,6 +195,19 @@ def conv3x3_dgrad_image(gy: L.View, w_oihw: torch.Tensor, n, h, w, dst: torch.Te
                                            1 if accumulate else 0), "tr_conv3x3_dgrad_image")
 
 
+def conv3x3_stem(img: torch.Tensor, w_oihw: torch.Tensor, bias: torch.Tensor | None, out: L.View, *, mean=None, std=None, pad_mode=L.PAD_ZEROS,
+                 act=L.ACT_NONE):
+    """3x3 stem conv straight from an NCHW fp32 image batch: normalise, pad, conv (cin <= 3), bias, ReLU -> NHWC fp32 view."""
+    _need_cuda(img, w_oihw, bias)
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.dim() == 4 and w_oihw.dtype == torch.float32 and w_oihw.is_contiguous()
+    n, cin, h, w = img.shape
+    cout = w_oihw.shape[0]
+    assert w_oihw.shape[1] == cin and tuple(w_oihw.shape[2:]) == (3, 3)
+    L.check(L.lib().tr_conv3x3_stem(stream_ptr(), img.data_ptr(), w_oihw.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                    _f3(mean) if mean is not None else None, _f3(std) if std is not None else None, cin, cout, n, h, w, pad_mode, act, out),
+            "tr_conv3x3_stem")
+
+
 def fold_replicate_nchw(gp: L.View, dst: torch.Tensor, ch_scale=None, accumulate=False):
     assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.dim() == 4
     n, c, h, w = dst.shape
