@@ -74,6 +74,8 @@ def check():
 def bench():
     shapes = [(16, 256, 256, 64, 32), (16, 256, 256, 96, 32), (16, 256, 256, 128, 32), (16, 256, 256, 160, 32), (16, 256, 256, 192, 64),
               (16, 1024, 1024, 64, 64), (16, 512, 512, 64, 64)]
+    if os.environ.get("N"):      # sub-batch A/B: the same layers at another batch size (does the working set fit the 256 MB Infinity Cache?)
+        shapes = [(int(os.environ["N"]),) + sh[1:] for sh in shapes]
     forms = sys.argv[2].split(",") if len(sys.argv) > 2 else ["lrelu", "mask", "res1"]
     for (n, h, w, cin, cout) in shapes:
         bufs = mk_bufs(n, h, w, cin, cout, torch.bfloat16, L.BF16)

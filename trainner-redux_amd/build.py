@@ -49,7 +49,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(HERE, "build", s.replace(".hip", ".o"))
         objs.append(o)
-        dev = ["-DTR_RING_DEV"] if os.environ.get("TRAINNER_DEV_BUILD") == "1" else []   # kernel development: fewer template instances
+        dev = ["-DTR_RING_DEV"] + (["-DTR_RING_STORE_AUX=" + os.environ["TR_AUX"]] if os.environ.get("TR_AUX") else []) if os.environ.get("TRAINNER_DEV_BUILD") == "1" else []   # kernel development: fewer template instances
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", *dev, "-Rpass-analysis=kernel-resource-usage", f"-I{INCLUDE}",
                f"-I{CSRC}", "-c", os.path.join(CSRC, s), "-o", o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -34,6 +34,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2c;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2c;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2c;
 
+#ifndef TR_RING_STORE_AUX
+#define TR_RING_STORE_AUX 0    /* cache policy bits of the epilogue stores (A/B: 2 = nt) */
+#endif
+#ifndef TR_RING_SPREAD
+#define TR_RING_SPREAD 1     /* A/B: 0 keeps the epilogue stages as blocks between MFMA steps */
+#endif
+
 constexpr int TW = 32;
 constexpr int HALO_W = TW + 2;
 constexpr unsigned OOB = 0x7fffff00u;        // beyond any num_records: the buffer load returns 0
@@ -138,9 +145,22 @@ __device__ __forceinline__ void ring_chunk_mfma_hooked(const char* hl, const cha
                 else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wa[cur][t]), __builtin_bit_cast(f16x8, xb[cur][r]), acc[r][t], 0, 0, 0);
             }
         if constexpr (NH > 0 && s >= 1 && (s - 1) % HS == 0 && (s - 1) / HS < NH) hook(std::integral_constant<int, HB + (s - 1) / HS>{});
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NH == 0 || !TR_RING_SPREAD) __builtin_amdgcn_sched_barrier(0);      // plain chunks: keep the fragment prefetch exactly one step ahead
     };
     static_for<NSTEP>(step);
+    if constexpr (NH > 0 && TR_RING_SPREAD) {
+        // Hooked chunks are ONE scheduling region: the epilogue stages (straight-line VALU / LDS / store code) are dealt out behind the MFMAs,
+        // a few instructions per MFMA, instead of sitting between two steps as blocks of 70-140 instructions during which the matrix pipe idles
+        // (a consumer wave has its SIMD to itself: whatever issues in the shadow of an MFMA -- ~5 instructions per 32-cycle MFMA -- is free).
+        auto grp = [&](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS read (operand fragments, strip read-back)
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // DS write (strip)
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);     // VMEM write
+        };
+        static_for<NSTEP * R * NT>(grp);
+    }
 }
 
 template <int CT, int NT, int R>
@@ -392,9 +412,13 @@ __device__ __forceinline__ void epi_finish_fast(const ConvArgs& a, const EpiTile
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         float v[8] = {rd[hf][0].x, rd[hf][0].y, rd[hf][0].z, rd[hf][0].w, rd[hf][1].x, rd[hf][1].y, rd[hf][1].z, rd[hf][1].w};
-        if constexpr (SIDE != 2) {   // LeakyReLU with slope in [0, 1] = max(v, v * slope) = med3(v, v * slope, +inf); act none: slope 1
+        if constexpr (SIDE != 2) {   // LeakyReLU with slope in [0, 1] = max(v, v * slope); act none: slope 1.  The raw instruction: fmaxf() puts a
+            // canonicalising v_max v, v, v in front of every maximum (3 instructions per element instead of 1.5 with the packed multiply)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i], v[i] * T.slope, __builtin_inff());
+            for (int i = 0; i < 8; ++i) {
+                const float vs = v[i] * T.slope;
+                asm("v_max_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[i]), "v"(vs));
+            }
         }
         if constexpr (SIDE == 2) {
             const uint4 qa = raw.q[hf * 4], qb = raw.q[hf * 4 + 1], qc = raw.q[hf * 4 + 2], qd = raw.q[hf * 4 + 3];
@@ -422,18 +446,18 @@ __device__ __forceinline__ void epi_finish_fast(const ConvArgs& a, const EpiTile
         // offset may have its data registers overwritten by the VALU instruction behind it (observed on gfx950: the packed multiply of the out2
         // scaling changed one element of the fp32 `out` piece of the last lanes of each row; loads have no such exposure).  Out-of-range stays
         // out of range: OOB + any image offset is below 2^32 and above every num_records.
-        const unsigned vo = (rowok ? (unsigned)T.c_out[hf] : OOB);
+        const unsigned vo = ((rowok && !(a.dbg & 4)) ? (unsigned)T.c_out[hf] : OOB);      // dbg 4 (TRAINNER_CONV_DBG, timing experiments): stores dropped by the bounds check
         if constexpr (SIDE == 2) {
             const unsigned so = (unsigned)(oyc * T.cs_out + t * 128);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, T.r_out, (int)(vo + so), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, T.r_out, (int)(vo + so + 16u), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, T.r_out, (int)(vo + so), 0, TR_RING_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, T.r_out, (int)(vo + so + 16u), 0, TR_RING_STORE_AUX);
             const float sc = a.out2_scale;
             const unsigned vo2 = (rowok ? (unsigned)T.c_out2[hf] : OOB) + (unsigned)(oyc * T.cs_out2 + t * 64);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2c<CT>(v[0] * sc, v[1] * sc), pack2c<CT>(v[2] * sc, v[3] * sc), pack2c<CT>(v[4] * sc, v[5] * sc), pack2c<CT>(v[6] * sc, v[7] * sc)},
-                                                   T.r_out2, (int)vo2, 0, 0);
+                                                   T.r_out2, (int)vo2, 0, TR_RING_STORE_AUX);
         } else {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2c<CT>(v[0], v[1]), pack2c<CT>(v[2], v[3]), pack2c<CT>(v[4], v[5]), pack2c<CT>(v[6], v[7])}, T.r_out,
-                                                   (int)(vo + (unsigned)(oyc * T.cs_out + t * 64)), 0, 0);
+                                                   (int)(vo + (unsigned)(oyc * T.cs_out + t * 64)), 0, TR_RING_STORE_AUX);
         }
     }
 }
