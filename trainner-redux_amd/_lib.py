@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
 ABI_VERSION = 1
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
+F32_WINOGRAD43 = 101    # ... tr_conv3x3_winograd43_f32 (F(4x4, 3x3), weights from tr_pack_winograd43)
 F32_WINOGRAD = 100      # ops.conv3x3 routes this pseudo compute code to tr_conv3x3_winograd_f32 (fp32 views, Winograd-packed weights)
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_GELU, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4, 5
 PAD_ZEROS, PAD_REPLICATE = 0, 1
@@ -108,6 +109,9 @@ SYMBOLS = {
     "tr_winograd_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "tr_pack_winograd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "tr_conv3x3_winograd_f32": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
+    "tr_winograd43_packed_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "tr_pack_winograd43": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "tr_conv3x3_winograd43_f32": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),
     "tr_conv3x3_dgrad_image": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_int]),
     "tr_conv3x3_stem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int,

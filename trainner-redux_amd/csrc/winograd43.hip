@@ -1,0 +1,312 @@
+// Winograd F(4x4, 3x3) convolution in fp32 arithmetic on MFMA, fully fused -- the second form of the fp32-forced VGG19 perceptual head
+// (reference: traiNNer/losses/perceptual_loss.py:8-12 casts the head's inputs to float32; perceptual_fp16_loss.py:262-329 is the conv / ReLU /
+// pool stack).  Y = A^T [ (G g G^T) (.) (B^T d B) ] A with 6 x 6 transformed tiles: 36 multiplies per 4 x 4 outputs instead of 144, i.e. 0.5625 of
+// the MFMA cycles of the F(2x2, 3x3) kernel (winograd.hip) and 0.25 of the direct form, at ~2e-6 relative error per layer in fp32 (F(2x2): 4e-7,
+// direct: 2e-7; measured against fp64 on VGG-shaped layers) -- every operation is an fp32 add / multiply / MFMA.
+//
+// Workgroup = 768 threads = 12 waves, one per CU; tile = 64 output channels x 32 Winograd tiles (4 x 8 tiles = 16 x 32 output pixels).
+// Wave (j, kh) owns column j of the 6 x 6 positions for output-channel half kh: six 32 x 32 accumulators (channel x tile), so the column fold
+// A^T M[:, j] of the output transform is register arithmetic.  K loop over 8-channel chunks, one barrier per chunk:
+//   * the transformed weights U never touch LDS: no two waves share an element, so a wave fetches the A fragments of its six positions straight
+//     from the packed array (16 bytes per lane and position, contiguous over the wave) and re-loads each position's registers for the next chunk
+//     right after its MFMAs (a rolling prefetch with a whole chunk of lead, no second register set);
+//   * only V = B^T d B goes through LDS (two 36 KB stages): the 18 x 34 x 8-channel halo of a chunk is fetched once per workgroup with 16-byte
+//     loads (three chunks in flight: loads of ch + 3, raw halo of ch + 2 in LDS, V of ch + 1, MFMAs on ch) and thread (tile, channel, row pair)
+//     builds two of the six rows of its 6 x 6 patch transform, one patch column behind each position's MFMAs;
+//   * epilogue: column fold in registers, one exchange round per channel half through LDS ([j][r][tile][36-float rows]), row fold
+//     Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int Q_TB = 32;                       // tiles per workgroup (4 rows x 8 cols of 4 x 4 output pixels)
+constexpr int Q_KB = 64;                       // output channels per workgroup
+constexpr int Q_CK = 8;                        // input channels per chunk
+constexpr int Q_THREADS = 768;
+constexpr int QV_FLOATS = 36 * 2 * Q_TB * 4;   // V of one chunk: [xi 36][kk 2][tile 32][s 4] (channel c = 2 s + kk) = 36 KB
+constexpr int Q_HR = 18, Q_HC = 34;            // halo rows / columns of the workgroup's input patch
+constexpr int Q_RS = 12;                       // floats per halo pixel in LDS (8 channels + 4: 16-byte aligned rows, 2-way read conflicts)
+constexpr int QRAW_FLOATS = Q_HR * Q_HC * Q_RS;
+constexpr int Q_TS = 36;                       // floats per (j, r, tile) row of the exchange buffer
+constexpr int QX_FLOATS = 6 * 4 * Q_TB * Q_TS; // one channel half: 110,592 B
+constexpr int QU_CHUNK = 12 * 6 * 256;         // packed U floats per (group, chunk): [wave 12][i 6][lane 64][e 4]
+constexpr int Q_SMEM = (2 * QV_FLOATS + 2 * QRAW_FLOATS) * 4;
+static_assert(QX_FLOATS * 4 <= Q_SMEM && Q_SMEM <= 160 * 1024, "LDS budget");
+
+struct Wino43Args {
+    int n, h, w, cin, cout;
+    int act;
+    float mask_slope;
+    tr_view in, out, mask;
+    const float* u;
+    const float* bias;
+    int nty, ntx, nchunks, nkg;
+};
+
+// one row of B^T d for the rows of the transform matrix B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ float bt_row(int i, const float (&d)[6]) {
+    switch (i) {
+        case 0: return 4.f * d[0] - 5.f * d[2] + d[4];
+        case 1: return -4.f * (d[1] + d[2]) + d[3] + d[4];
+        case 2: return 4.f * (d[1] - d[2]) - d[3] + d[4];
+        case 3: return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+        case 4: return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+        default: return 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+}
+
+__global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* vst = (float*)smem;                       // two V stages
+    float* rawb = vst + 2 * QV_FLOATS;               // two raw halo buffers
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = l & 31, lh = l >> 5;
+    const int wj = wv % 6, wkh = wv / 6;
+    int b = blockIdx.x;
+    const int kg = b % a.nkg; b /= a.nkg;          // output-channel group fastest: neighbours in the grid share the input patch in L2
+    const int bx = b % a.ntx; b /= a.ntx;
+    const int by = b % a.nty;
+    const int nb = b / a.nty;
+
+    // ---- loader role: the 18 x 34 x 8-channel halo as 1224 16-byte pieces, one or two per thread (zero padding applied on the way into LDS)
+    const float* inimg = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff;
+    int roff[2], rdst[2];
+    bool rok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = tid + j * Q_THREADS;
+        const int pix = min(piece, Q_HR * Q_HC * 2 - 1) >> 1, half = piece & 1;
+        const int hy = pix / Q_HC, hx = pix - hy * Q_HC;
+        const int y = by * 16 - 1 + hy, x = bx * 32 - 1 + hx;
+        rok[j] = y >= 0 && y < a.h && x >= 0 && x < a.w;
+        roff[j] = (min(max(y, 0), a.h - 1) * a.w + min(max(x, 0), a.w - 1)) * a.in.cstride + half * 4;
+        rdst[j] = pix * Q_RS + half * 4;
+    }
+    const bool second = tid < Q_HR * Q_HC * 2 - Q_THREADS;
+    f32x4 rawreg[2];
+    auto issue_in = [&](int ch) {                // ch may run past the last chunk (clamped: a redundant load instead of a branch)
+        const float* src = inimg + min(ch, a.nchunks - 1) * Q_CK;
+        rawreg[0] = *(const f32x4*)(src + roff[0]);
+        rawreg[1] = *(const f32x4*)(src + roff[1]);
+    };
+    auto put_raw = [&](float* rb) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(rb + rdst[0]) = rok[0] ? rawreg[0] : z;
+        if (second) *(f32x4*)(rb + rdst[1]) = rok[1] ? rawreg[1] : z;
+    };
+
+    // ---- fill role: (tile ft, channel fc) of the chunk, rows fi and fi + 3 of its 6 x 6 transform (fi is uniform per wave) -------------------
+    const int fc = tid & 7, ft = (tid >> 3) & 31;
+    const int fi = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int rsrc = (((ft >> 3) * 4) * Q_HC + (ft & 7) * 4) * Q_RS + fc;            // top-left value of this thread's patch in a raw buffer
+    const int vdst = (((fc & 1) * Q_TB) + ft) * 4 + (fc >> 1);                       // + xi * 256 floats within a stage
+    float ta[6], tb[6];
+    auto fill_col = [&](const float* rb, int col) {      // column `col` of the patch -> entry `col` of the two B^T d rows
+        float d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = rb[rsrc + (k * Q_HC + col) * Q_RS];
+        ta[col] = bt_row(fi, d);
+        tb[col] = bt_row(fi + 3, d);
+    };
+    auto fill_rows = [&](float* st) {                    // (B^T d) B for the two rows, into the 2 x 6 positions of the stage
+        float* va = st + vdst + (fi * 6) * 256;
+        float* vb = st + vdst + ((fi + 3) * 6) * 256;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            va[j * 256] = bt_row(j, ta);                 // V[i][j] = sum_l t[l] B^T[j][l]
+            vb[j * 256] = bt_row(j, tb);
+        }
+    };
+
+    // ---- MFMA role ---------------------------------------------------------------------------------------------------------------------------
+    const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256) + l * 4;      // + chunk * QU_CHUNK + i * 256
+    f32x4 ureg[6];
+    f32x16 acc[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    issue_in(0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ureg[i] = *(const f32x4*)(ub + i * 256);
+    put_raw(rawb);
+    issue_in(1);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 6; ++c) fill_col(rawb, c);
+    fill_rows(vst);
+    put_raw(rawb + QRAW_FLOATS);
+    issue_in(2);
+    __syncthreads();
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
+        float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
+        const float* rb = rawb + ((ch + 1) & 1) * QRAW_FLOATS;
+        const float* un = ub + (int64_t)min(ch + 1, a.nchunks - 1) * QU_CHUNK;
+        f32x4 bv[2];
+        bv[0] = *(const f32x4*)(vl + wj * 256);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i + 1 < 6) bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i][e], bv[i & 1][e], acc[i], 0, 0, 0);
+            ureg[i] = *(const f32x4*)(un + i * 256);      // this position's weights of the next chunk: a whole chunk of lead
+            fill_col(rb, i);                              // one patch column of the next stage behind every position
+            if (i == 2) {
+                put_raw(rawb + (ch & 1) * QRAW_FLOATS);   // chunk ch + 2; this buffer's previous content (chunk ch) was consumed an iteration ago
+                issue_in(ch + 3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        fill_rows(nst);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- output transform + epilogue ----------------------------------------------------------------------------------------------------------
+    // column fold T[r] = sum_i A^T[r][i] M[i][j], A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], written per 4-register group
+    float* tl = (float*)smem;
+    const int ek4 = (tid & 7) * 4, erp = (tid >> 3) & 1, et = tid >> 4;     // finishing role (threads < 512): channel quad, row pair, tile
+    const int ty = et >> 3, tx = et & 7;
+#pragma unroll 1
+    for (int round = 0; round < 2; ++round) {
+        if (wkh == round) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t0, t1, t2, t3;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a0 = acc[0][q * 4 + e], a1 = acc[1][q * 4 + e], a2 = acc[2][q * 4 + e], a3 = acc[3][q * 4 + e], a4 = acc[4][q * 4 + e],
+                                a5 = acc[5][q * 4 + e];
+                    const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+                    t0[e] = a0 + s12 + s34;
+                    t1[e] = d12 + 2.f * d34;
+                    t2[e] = s12 + 4.f * s34;
+                    t3[e] = d12 + 8.f * d34 + a5;
+                }
+                float* dst = tl + ((wj * 4) * Q_TB + lr) * Q_TS + q * 8 + lh * 4;
+                *(f32x4*)(dst) = t0;
+                *(f32x4*)(dst + 1 * Q_TB * Q_TS) = t1;
+                *(f32x4*)(dst + 2 * Q_TB * Q_TS) = t2;
+                *(f32x4*)(dst + 3 * Q_TB * Q_TS) = t3;
+            }
+        }
+        __syncthreads();
+        if (tid < 512) {
+            const int kc = kg * Q_KB + round * 32 + ek4;
+            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias = *(const f32x4*)(a.bias + kc);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = erp * 2 + rr;
+                const float* tp = tl + (r * Q_TB + et) * Q_TS + ek4;
+                f32x4 T[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) T[j] = *(const f32x4*)(tp + j * 4 * Q_TB * Q_TS);
+                const f32x4 s12 = T[1] + T[2], d12 = T[1] - T[2], s34 = T[3] + T[4], d34 = T[3] - T[4];
+                const f32x4 y[4] = {T[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + T[5]};
+                const int oy = by * 16 + ty * 4 + r;
+                if (oy >= a.h) continue;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int ox = bx * 32 + tx * 4 + s;
+                    if (ox >= a.w) continue;
+                    const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
+                    f32x4 v = y[s] + bias;
+                    if (a.act == TR_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (a.mask.ptr) {
+                        const f32x4 m = *(const f32x4*)((const float*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + kc);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= m[e] > 0.f ? 1.f : a.mask_slope;
+                    }
+                    *(f32x4*)((float*)a.out.ptr + pix * a.out.cstride + a.out.coff + kc) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], for g = w[co][ci] (or, transposed, the
+// input-gradient kernel w[ci][co] with its taps mirrored), in the kernel's fragment order [co / 64][ci / 8][wave = (co % 64 / 32) * 6 + j][i]
+// [lane = (ci & 1) * 32 + co % 32][e = (ci % 8) >> 1].
+__global__ __launch_bounds__(256) void winograd43_pack_kernel(const float* __restrict__ w, float* __restrict__ dst, int cout, int cin, int src_i, int transpose) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)cout * cin) return;
+    const int co = (int)(idx / cin), ci = (int)(idx % cin);
+    float g[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t] = transpose ? w[((int64_t)ci * src_i + co) * 9 + (8 - t)] : w[((int64_t)co * src_i + ci) * 9 + t];
+    const float G[6][3] = {{0.25f, 0.f, 0.f}, {-1.f / 6, -1.f / 6, -1.f / 6}, {-1.f / 6, 1.f / 6, -1.f / 6}, {1.f / 24, 1.f / 12, 1.f / 6},
+                           {1.f / 24, -1.f / 12, 1.f / 6}, {0.f, 0.f, 1.f}};
+    float gg[6][3];                                          // G g
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int x = 0; x < 3; ++x) gg[i][x] = G[i][0] * g[0 + x] + G[i][1] * g[3 + x] + G[i][2] * g[6 + x];
+    const int nchunks = cin / Q_CK, cc = ci % Q_CK, col = co % Q_KB;
+    const int lane = (cc & 1) * 32 + (col & 31), e = cc >> 1, kh = col >> 5;
+    float* base = dst + ((int64_t)(co / Q_KB) * nchunks + ci / Q_CK) * QU_CHUNK + lane * 4 + e;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) base[((kh * 6 + j) * 6 + i) * 256] = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
+}
+
+inline bool q_view_ok(const tr_view& v, int c) { return v.ptr && v.dtype == TR_F32 && v.c >= c && v.coff >= 0 && v.coff + c <= v.cstride; }
+
+}  // namespace
+
+extern "C" size_t tr_winograd43_packed_bytes(int cin, int cout) { return (size_t)cin * cout * 36 * sizeof(float); }
+
+extern "C" int tr_pack_winograd43(void* stream, const float* w_oihw, float* dst, int cout, int cin, int transpose) {
+    TR_REQUIRE(w_oihw && dst && cout > 0 && cin > 0 && cout % Q_KB == 0 && cin % Q_CK == 0, TR_EINVAL,
+               "tr_pack_winograd43: cout=%d must be a multiple of %d and cin=%d of %d", cout, Q_KB, cin, Q_CK);
+    TR_REQUIRE(((uintptr_t)dst) % 16 == 0, TR_EALIGN, "tr_pack_winograd43: dst must be 16-byte aligned");
+    const int64_t n = (int64_t)cout * cin;
+    // the OIHW source is cout x cin (direct) or cin x cout (transpose: the input-gradient conv of that weight)
+    hipLaunchKernelGGL(winograd43_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, dst, cout, cin,
+                       transpose ? cout : cin, transpose ? 1 : 0);
+    return tr::launch_status("tr_pack_winograd43");
+}
+
+extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d) {
+    TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_conv3x3_winograd43_f32: null descriptor");
+    TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->h % 4 == 0 && d->w % 4 == 0, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: needs output dims that are multiples of 4 (got %dx%d)", d->h, d->w);
+    TR_REQUIRE(d->cin > 0 && d->cin % Q_CK == 0 && d->cout > 0 && d->cout % Q_KB == 0, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: cin=%d must be a multiple of %d and cout=%d of %d", d->cin, Q_CK, d->cout, Q_KB);
+    TR_REQUIRE(d->ksize == 3 && d->in_mode == TR_IN_DIRECT && d->pad_mode == TR_PAD_ZEROS, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: 3x3, direct input, zero padding only");
+    TR_REQUIRE(d->act == TR_ACT_NONE || d->act == TR_ACT_RELU, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: activation %d is not built (none, ReLU)", d->act);
+    TR_REQUIRE(!d->res1.ptr && !d->res2.ptr && !d->out2.ptr && !d->sample_scale && d->mask_mode == 0, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: residual / second output / per-sample scale / activation-derivative masks are not built");
+    TR_REQUIRE(q_view_ok(d->in, d->cin) && q_view_ok(d->out, d->cout) && (!d->mask.ptr || q_view_ok(d->mask, d->cout)) && d->wpacked, TR_EINVAL,
+               "tr_conv3x3_winograd43_f32: fp32 views holding cin / cout channels and packed weights are required");
+    TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3_winograd43_f32: wpacked must be 16-byte aligned");
+    auto al = [](const tr_view& v) { return !v.ptr || (v.cstride % 4 == 0 && v.coff % 4 == 0 && ((uintptr_t)v.ptr) % 16 == 0); };
+    TR_REQUIRE(al(d->in) && al(d->out) && al(d->mask), TR_EALIGN, "tr_conv3x3_winograd43_f32: views must allow aligned 4-channel access");
+    TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride < (int64_t)0x7fffffff, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: one image of the input must stay below 2^31 elements");
+    Wino43Args a;
+    a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
+    a.act = d->act; a.mask_slope = d->mask_slope;
+    a.in = d->in; a.out = d->out; a.mask = d->mask;
+    a.u = (const float*)d->wpacked; a.bias = d->bias;
+    a.nty = (d->h + 15) / 16; a.ntx = (d->w + 31) / 32;
+    a.nchunks = d->cin / Q_CK; a.nkg = d->cout / Q_KB;
+    const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
+    TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: grid too large");
+    static const hipError_t attr = hipFuncSetAttribute((const void*)winograd43_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+    TR_REQUIRE(attr == hipSuccess, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: the device does not grant %d bytes of LDS per workgroup", Q_SMEM);
+    hipLaunchKernelGGL(winograd43_f32_kernel, dim3((unsigned)nblk), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    return tr::launch_status("tr_conv3x3_winograd43_f32");
+}

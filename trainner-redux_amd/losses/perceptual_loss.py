@@ -102,6 +102,7 @@ class VGG(nn.Module):
         # exact-fp32 convs run as fused Winograd F(2x2, 3x3) MFMA kernels (same arithmetic type, 2.25x fewer multiplies, ~1e-6 from the
         # direct sum); TRAINNER_VGG_WINOGRAD=0 keeps the direct kernel
         self.winograd = os.environ.get("TRAINNER_VGG_WINOGRAD", "1") != "0"
+        self.winograd43 = os.environ.get("TRAINNER_VGG_WINOGRAD", "1") not in ("0", "2")       # "2": F(2x2, 3x3) only
 
     # -- weights ------------------------------------------------------------------------------------------
     def init_synthetic(self, seed: int = 0) -> None:
@@ -190,6 +191,9 @@ class VGG(nn.Module):
                 # exact-fp32 mode: the fused Winograd F(2x2, 3x3) kernel (csrc/winograd.hip) for every conv but the replicate-padded stem;
                 # forward slab and the slab of the input-gradient conv (VGG weights are frozen: packed once)
                 pk[name] = (f, b, ops.pack_winograd(m.weight.data), ops.pack_winograd(m.weight.data, transpose=True))
+                if self.winograd43:
+                    # F(4x4, 3x3) slabs (csrc/winograd43.hip): 0.5625 of the MFMA cycles, ~2e-6 per layer instead of ~4e-7; used where h and w are multiples of 4
+                    pk[name] = pk[name] + (ops.pack_winograd43(m.weight.data), ops.pack_winograd43(m.weight.data, transpose=True))
         plan.finalize().run()
         self._packs = ((cd, str(dev)), pk, plan)
         return pk
@@ -245,13 +249,14 @@ class VGG(nn.Module):
                     out = ws["scratch"][flip].view(-1)[: n * hh * ww * m.cout].view(n, hh, ww, m.cout)
                     flip ^= 1
                 wino = len(pk[name]) > 2 and not first and hh % 2 == 0 and ww % 2 == 0
+                w43 = wino and len(pk[name]) > 4 and hh % 4 == 0 and ww % 4 == 0
                 if first and stem:
                     ops.conv3x3_stem(img.contiguous(), m.weight.data, m.bias.data, V(out), mean=IMAGENET_MEAN, std=IMAGENET_STD, pad_mode=L.PAD_REPLICATE,
                                      act=L.ACT_RELU if fused_relu else L.ACT_NONE)
                 else:
-                    ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD if wino else cd, inp=V(cur, 0, cur_c), out=V(out),
-                                wpacked=pk[name][2 if wino else 0], bias=m.bias.data, act=L.ACT_RELU if fused_relu else L.ACT_NONE,
-                                pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
+                    ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD43 if w43 else L.F32_WINOGRAD if wino else cd,
+                                inp=V(cur, 0, cur_c), out=V(out), wpacked=pk[name][4 if w43 else 2 if wino else 0], bias=m.bias.data,
+                                act=L.ACT_RELU if fused_relu else L.ACT_NONE, pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
                 first = False
                 cur, cur_c = out, m.cout
             else:
@@ -336,8 +341,9 @@ class VGG(nn.Module):
             gin = dst_buf.view(-1)[: inp_act.numel()].view(inp_act.shape)
             mask = V(inp_act) if (prev[0] == "conv" and prev[3]) else ops.NULL_VIEW
             wino = len(pk[name]) > 2 and hh % 2 == 0 and ww % 2 == 0
-            ops.conv3x3(n=n, h=hh, w=ww, cin=m.cout, cout=m.cin, compute=L.F32_WINOGRAD if wino else cd, inp=V(g), out=V(gin),
-                        wpacked=pk[name][3 if wino else 1], mask=mask, mask_slope=0.0)
+            w43 = wino and len(pk[name]) > 4 and hh % 4 == 0 and ww % 4 == 0
+            ops.conv3x3(n=n, h=hh, w=ww, cin=m.cout, cout=m.cin, compute=L.F32_WINOGRAD43 if w43 else L.F32_WINOGRAD if wino else cd, inp=V(g), out=V(gin),
+                        wpacked=pk[name][5 if w43 else 3 if wino else 1], mask=mask, mask_slope=0.0)
             g = gin
         return names
 

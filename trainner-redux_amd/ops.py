@@ -78,6 +78,10 @@ def conv3x3(*, n, h, w, cin, cout, compute, inp: L.View, out: L.View, wpacked: t
         d.compute = L.F32
         L.check(L.lib().tr_conv3x3_winograd_f32(stream_ptr(), C.byref(d)), "tr_conv3x3_winograd_f32")
         return
+    if compute == L.F32_WINOGRAD43:
+        d.compute = L.F32
+        L.check(L.lib().tr_conv3x3_winograd43_f32(stream_ptr(), C.byref(d)), "tr_conv3x3_winograd43_f32")
+        return
     L.check(L.lib().tr_conv3x3(stream_ptr(), C.byref(d)), "tr_conv3x3")
 
 
@@ -92,6 +96,20 @@ def pack_winograd(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor
     cout, cin = (i, o) if transpose else (o, i)
     dst = torch.empty(cin * cout * 16, dtype=torch.float32, device=weight.device)
     L.check(L.lib().tr_pack_winograd(stream_ptr(), weight.data_ptr(), dst.data_ptr(), cout, cin, 1 if transpose else 0), "tr_pack_winograd")
+    return dst
+
+
+def winograd43_eligible(cin: int, cout: int, h: int, w: int) -> bool:
+    return cin % 8 == 0 and cout % 64 == 0 and h % 4 == 0 and w % 4 == 0
+
+
+def pack_winograd43(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """fp32 OIHW 3x3 weight -> F(4x4, 3x3) Winograd-domain slab of tr_conv3x3_winograd43_f32 (transpose: the slab of the input-gradient conv)."""
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.dim() == 4 and weight.shape[2:] == (3, 3)
+    o, i = weight.shape[:2]
+    cout, cin = (i, o) if transpose else (o, i)
+    dst = torch.empty(cin * cout * 36, dtype=torch.float32, device=weight.device)
+    L.check(L.lib().tr_pack_winograd43(stream_ptr(), weight.data_ptr(), dst.data_ptr(), cout, cin, 1 if transpose else 0), "tr_pack_winograd43")
     return dst
 
 
