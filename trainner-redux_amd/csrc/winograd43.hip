@@ -104,27 +104,44 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
     const int fi = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int rsrc = (((ft >> 3) * 4) * Q_HC + (ft & 7) * 4) * Q_RS + fc;            // top-left value of this thread's patch in a raw buffer
     const int vdst = (((fc & 1) * Q_TB) + ft) * 4 + (fc >> 1);                       // + xi * 256 floats within a stage
+    // the two B^T rows of this wave as scalars (fi is wave uniform): one FMA chain per row and column, no branches in the K loop (a `switch` on
+    // the row index cost 13 scalar branches per chunk and broke the loop body into basic blocks the scheduler could not interleave with the MFMAs)
+    float ca[6], cb[6];
+    {
+        const float BT[6][6] = {{4.f, 0.f, -5.f, 0.f, 1.f, 0.f}, {0.f, -4.f, -4.f, 1.f, 1.f, 0.f}, {0.f, 4.f, -4.f, -1.f, 1.f, 0.f},
+                                {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, 4.f, 0.f, -5.f, 0.f, 1.f}};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ca[k] = fi == 0 ? BT[0][k] : fi == 1 ? BT[1][k] : BT[2][k];
+            cb[k] = fi == 0 ? BT[3][k] : fi == 1 ? BT[4][k] : BT[5][k];
+        }
+    }
     float ta[6], tb[6];
     auto fill_col = [&](const float* rb, int col) {      // column `col` of the patch -> entry `col` of the two B^T d rows
         float d[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = rb[rsrc + (k * Q_HC + col) * Q_RS];
-        ta[col] = bt_row(fi, d);
-        tb[col] = bt_row(fi + 3, d);
-    };
-    auto fill_rows = [&](float* st) {                    // (B^T d) B for the two rows, into the 2 x 6 positions of the stage
-        float* va = st + vdst + (fi * 6) * 256;
-        float* vb = st + vdst + ((fi + 3) * 6) * 256;
+        float xa = ca[0] * d[0], xb = cb[0] * d[0];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            va[j * 256] = bt_row(j, ta);                 // V[i][j] = sum_l t[l] B^T[j][l]
-            vb[j * 256] = bt_row(j, tb);
+        for (int k = 1; k < 6; ++k) {
+            xa += ca[k] * d[k];
+            xb += cb[k] * d[k];
         }
+        ta[col] = xa;
+        tb[col] = xb;
+    };
+    auto fill_row_out = [&](float* st, int j) {          // (B^T d) B: output column j of the two rows, into the stage
+        st[vdst + (fi * 6 + j) * 256] = bt_row(j, ta);   // V[i][j] = sum_l t[l] B^T[j][l]
+        st[vdst + ((fi + 3) * 6 + j) * 256] = bt_row(j, tb);
+    };
+    auto fill_rows = [&](float* st) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) fill_row_out(st, j);
     };
 
     // ---- MFMA role ---------------------------------------------------------------------------------------------------------------------------
     const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256) + l * 4;      // + chunk * QU_CHUNK + i * 256
-    f32x4 ureg[6];
+    f32x4 ureg[3];                                   // ring: position p lives in ureg[p % 3] and is requested two positions ahead of its MFMAs
     f32x16 acc[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -132,8 +149,8 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     issue_in(0);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) ureg[i] = *(const f32x4*)(ub + i * 256);
+    ureg[0] = *(const f32x4*)(ub);
+    ureg[1] = *(const f32x4*)(ub + 256);
     put_raw(rawb);
     issue_in(1);
     __syncthreads();
@@ -147,23 +164,31 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
         const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
         float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
         const float* rb = rawb + ((ch + 1) & 1) * QRAW_FLOATS;
+        const float* uc = ub + (int64_t)ch * QU_CHUNK;
         const float* un = ub + (int64_t)min(ch + 1, a.nchunks - 1) * QU_CHUNK;
         f32x4 bv[2];
         bv[0] = *(const f32x4*)(vl + wj * 256);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             if (i + 1 < 6) bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
+            // weights two positions ahead (positions 4 and 5 request positions 0 and 1 of the next chunk)
+            ureg[(i + 2) % 3] = i + 2 < 6 ? *(const f32x4*)(uc + (i + 2) * 256) : *(const f32x4*)(un + (i + 2 - 6) * 256);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i][e], bv[i & 1][e], acc[i], 0, 0, 0);
-            ureg[i] = *(const f32x4*)(un + i * 256);      // this position's weights of the next chunk: a whole chunk of lead
-            fill_col(rb, i);                              // one patch column of the next stage behind every position
+            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i % 3][e], bv[i & 1][e], acc[i], 0, 0, 0);
+            // the next stage's fill rides behind the MFMAs: two patch columns behind each of positions 0-2, two output columns behind each of 3-5
+            if (i < 3) {
+                fill_col(rb, 2 * i);
+                fill_col(rb, 2 * i + 1);
+            } else {
+                fill_row_out(nst, 2 * (i - 3));
+                fill_row_out(nst, 2 * (i - 3) + 1);
+            }
             if (i == 2) {
                 put_raw(rawb + (ch & 1) * QRAW_FLOATS);   // chunk ch + 2; this buffer's previous content (chunk ch) was consumed an iteration ago
                 issue_in(ch + 3);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        fill_rows(nst);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
