@@ -7,14 +7,20 @@ sys.path.insert(0, __file__.rsplit("/", 1)[0])
 from prof_summary import pmc
 
 fe, wr = pmc(sys.argv[1], "FETCH_SIZE"), pmc(sys.argv[2], "WRITE_SIZE")
-out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_traffic_headline.txt): (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 "
+out = {"_comment": "HBM bytes per launch from rocprofv3 PMC passes (profiles/r02_pmc_traffic_headline.txt): (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 "
                    "FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section); workload = bench.py default (ESRGAN l1+perceptual bf16 256->1024 batch 16)",
        "workload": "l1+perceptual/bf16/batch16/lq256/blocks23"}
 groups = {}
 for k in fe:
     m = re.search(r"conv3x3_kernel_reg<(\d), (\d), (\d), 3>", k)
-    if "winograd_f32_kernel" in k:
+    mr = re.search(r"conv_ring_kernel<(\d), (\d),", k)
+    if "winograd43_f32_kernel" in k:
+        key = "f32/winograd43"
+    elif "winograd_f32_kernel" in k:
         key = "f32/winograd"
+    elif mr:     # the LDS-DMA ring kernels: same grouping as bench.py's per-launch timers (compute dtype / output-group width)
+        ct, nt = int(mr.group(1)), int(mr.group(2))
+        key = ("f32" if ct == 0 else "bf16" if ct == 1 else "f16") + ("/cg64" if nt == 2 else "/cg32")
     elif not m:
         continue
     else:
