@@ -373,6 +373,31 @@ def test_stem_input_gradient_full_mode_and_replicate_fold(cuda, compute_name):
 
 
 @pytest.mark.parametrize("pad", ["replicate", "zeros"])
+@pytest.mark.parametrize("shape", [(2, 14, 38, 64, 0), (1, 8, 32, 64, 0), (1, 1, 5, 64, 0), (3, 40, 65, 64, 16), (1, 9, 12, 32, 0)])
+def test_stem_input_gradient_tiled_kernel(cuda, pad, shape):
+    """tr_conv3x3_dgrad_image (input gradient of VGG19 conv1_1, perceptual_fp16_loss.py:272-274,322 under autograd): cout = 64 fp32 takes the
+    LDS-tiled kernel (partial tiles, one-row images, border folding of replicate padding, a channel slice of a wider buffer, accumulate);
+    cout = 32 takes the per-pixel reference kernel.  fp32 FMA chains in another order than autograd's: 3e-6."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w, cout, coff = shape
+    g = torch.Generator().manual_seed(n * 100 + h + w)
+    img = torch.rand(n, 3, h, w, generator=g).requires_grad_(True)
+    wt = torch.randn(cout, 3, 3, 3, generator=g) / 5
+    gy = torch.randn(n, cout, h, w, generator=g)
+    std = (0.229, 0.224, 0.225)
+    xin = img / torch.tensor(std).view(1, 3, 1, 1)
+    xp = F.pad(xin, (1, 1, 1, 1), mode="replicate") if pad == "replicate" else F.pad(xin, (1, 1, 1, 1))
+    F.conv2d(xp, wt).backward(gy)
+    buf = torch.randn(n, h, w, cout + coff + 4, generator=g).to(cuda)
+    buf[..., coff:coff + cout] = nhwc(gy).to(cuda)
+    out = torch.full((n, 3, h, w), 2.0, device=cuda)
+    ops.conv3x3_dgrad_image(ops.view(buf, coff, cout), wt.to(cuda), n, h, w, out, pad_mode=L.PAD_REPLICATE if pad == "replicate" else L.PAD_ZEROS,
+                            ch_scale=[1 / s for s in std], accumulate=True)
+    assert rel_l2(out.cpu() - 2.0, img.grad) < 3e-6
+
+
+@pytest.mark.parametrize("pad", ["replicate", "zeros"])
 @pytest.mark.parametrize("shape", [(2, 14, 38, 64, True), (1, 9, 7, 64, False), (1, 33, 20, 24, True), (1, 8, 16, 128, True)])
 def test_stem_conv_from_nchw_image(cuda, pad, shape):
     """tr_conv3x3_stem (VGG19 conv1_1, perceptual_fp16_loss.py:272-274,322): normalise + pad + 3x3 conv + bias + ReLU straight from the NCHW

@@ -62,6 +62,123 @@ __global__ __launch_bounds__(256) void dgrad_image_kernel(tr_view gy, const floa
     }
 }
 
+// Tiled form of the above for the shape that matters (VGG19 conv1_1: 64 -> 3 channels, fp32 gradient at the generator's output size):
+// workgroup = 8 x 32 output pixels, one thread per pixel.  The 10 x 34 halo of gy goes through LDS 32 channels at a time (48 KB, three
+// workgroups per CU, so one workgroup's staging overlaps its neighbours' FMAs); the weights are read in OIHW order with wave-uniform
+// addresses (108 contiguous floats per channel quad -> scalar loads, FMAs take them as SGPR operands).  Algorithmic traffic = gy once
+// (256 B per pixel) + 12 B of output; the MFMA 'full'-mode conv it replaces spent 29 of 32 N-lanes on zeros and a second pass to fold.
+__global__ __launch_bounds__(256) void dgrad_image_tiled_kernel(tr_view gy, const float* __restrict__ w, int n, int h, int wd, int replicate, float4 chs,
+                                                                 float* __restrict__ dst, int accumulate, int ntx, int nty) {
+    constexpr int PS = 36;   // floats per staged pixel: 32 channels + 4 of padding (16-byte reads of a row of lanes hit distinct banks)
+    __shared__ float gl[10 * 34 * PS];
+    const int col = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const float* g = (const float*)gy.ptr;
+    const int64_t hw = (int64_t)h * wd;
+    const int ntiles = n * ntx * nty;
+    // software pipeline over (tile, channel half) steps: the loads of step s+1 are issued before the FMAs of step s and land in LDS after them
+    const int q8 = threadIdx.x & 7, c8 = threadIdx.x >> 3;
+    float4 sv[11];
+    auto issue = [&](int tile, int half) {
+        int t_ = tile;
+        const int x0 = (t_ % ntx) * 32; t_ /= ntx;
+        const int y0 = (t_ % nty) * 8;
+        const int nb = t_ / nty;
+        const float* gb = g + (int64_t)nb * hw * gy.cstride + gy.coff + half * 32 + q8 * 4;
+        int r = 0, c = c8;
+#pragma unroll
+        for (int pass = 0; pass < 11; ++pass) {   // 340 halo pixels x 8 float4, thread = (pixel % 32, q); branch-free so the 11 loads fly together
+            const int y = y0 + r - 1, x = x0 + c - 1;
+            const bool ok = r < 10 && y >= 0 && y < h && x >= 0 && x < wd;
+            const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), wd - 1);
+            sv[pass] = *(const float4*)(gb + ((int64_t)yc * wd + xc) * gy.cstride);
+            if (!ok) sv[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+            c += 32;
+            if (c >= 34) { c -= 34; ++r; }
+        }
+    };
+    auto land = [&]() {
+        int r = 0, c = c8;
+#pragma unroll
+        for (int pass = 0; pass < 11; ++pass) {
+            if (r < 10) *(float4*)(gl + (r * 34 + c) * PS + q8 * 4) = sv[pass];
+            c += 32;
+            if (c >= 34) { c -= 34; ++r; }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue(blockIdx.x, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t_ = tile;
+        const int x0 = (t_ % ntx) * 32; t_ /= ntx;
+        const int y0 = (t_ % nty) * 8;
+        const int nb = t_ / nty;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                     // the previous step's FMAs have read the stage
+            land();
+            __syncthreads();
+            if (half == 0) issue(tile, 1);
+            else if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x, 0);
+            // gp(py,px) reads gy[py-ky+1, px-kx+1] = staged pixel (row + 2 - ky, col + 2 - kx)
+            const float* lp = gl + ((row + 2) * 34 + col + 2) * PS;
+            for (int q = 0; q < 8; ++q) {
+                const float* wq = w + (half * 32 + q * 4) * 27;       // wave-uniform: [co 4][ci 3][tap 9]
+                float4 v[9];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = *(const float4*)(lp - (ky * 34 + kx) * PS + q * 4);
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {          // two channels (54 scalar weights) at a time: all 108 at once spill SGPRs
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float gv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+                        for (int j = jp * 2; j < jp * 2 + 2; ++j)
+#pragma unroll
+                            for (int ci = 0; ci < 3; ++ci) acc[ci] += gv[j] * wq[(j * 3 + ci) * 9 + t];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const int oy = y0 + row, ox = x0 + col;
+        if (oy >= h || ox >= wd) continue;
+        if (replicate && (oy == 0 || oy == h - 1 || ox == 0 || ox == wd - 1)) {
+            // border pixels also collect the padded positions that were filled from them (4 in 1024 pixels: straight from global memory)
+            const int ny0 = oy == 0 ? -1 : oy, ny1 = oy == h - 1 ? h : oy;
+            const int nx0 = ox == 0 ? -1 : ox, nx1 = ox == wd - 1 ? wd : ox;
+            for (int py = ny0; py <= ny1; ++py)
+                for (int px = nx0; px <= nx1; ++px) {
+                    if (py == oy && px == ox) continue;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int qy = py - ky + 1;
+                        if (qy < 0 || qy >= h) continue;
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int qx = px - kx + 1;
+                            if (qx < 0 || qx >= wd) continue;
+                            const float* gp = g + (((int64_t)nb * h + qy) * wd + qx) * gy.cstride + gy.coff;
+                            for (int co = 0; co < 64; co += 4) {
+                                const float4 v = *(const float4*)(gp + co);
+                                const float gv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int ci = 0; ci < 3; ++ci) acc[ci] += gv[j] * w[((co + j) * 3 + ci) * 9 + ky * 3 + kx];
+                            }
+                        }
+                    }
+                }
+        }
+        const float sc[3] = {chs.x, chs.y, chs.z};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float* o = dst + ((int64_t)nb * 3 + c) * hw + (int64_t)oy * wd + ox;
+            const float v = acc[c] * sc[c];
+            *o = accumulate ? *o + v : v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fold_replicate_kernel(tr_view gp, float* __restrict__ dst, int n, int c, int h, int w, float4 chs,
                                                              int accumulate) {
     const int64_t hw = (int64_t)h * w, total = (int64_t)n * hw;
@@ -185,6 +302,13 @@ extern "C" int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_o
         float t[4] = {1.f, 1.f, 1.f, 1.f};
         for (int i = 0; i < cin; ++i) t[i] = ch_scale[i];
         chs = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    if (cout == 64 && cin == 3 && gy.dtype == TR_F32 && tr::view_vec4_ok(gy) && !getenv("TRAINNER_DGRAD_IMAGE_REF")) {
+        const int ntx = (w + 31) / 32, nty = (h + 7) / 8;
+        const int64_t tiles = (int64_t)n * ntx * nty;
+        hipLaunchKernelGGL(dgrad_image_tiled_kernel, dim3((unsigned)(tiles < 256 * 24 ? tiles : 256 * 24)), dim3(256), 0, (hipStream_t)stream, gy, w_oihw, n,
+                           h, w, pad_mode == TR_PAD_REPLICATE, chs, dst_nchw, accumulate, ntx, nty);
+        return tr::launch_status("tr_conv3x3_dgrad_image");
     }
     const int64_t total = (int64_t)n * h * w;
     int64_t blocks = (total + 255) / 256;

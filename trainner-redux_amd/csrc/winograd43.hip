@@ -29,8 +29,14 @@ constexpr int Q_CK = 8;                        // input channels per chunk
 constexpr int Q_THREADS = 768;
 constexpr int QV_FLOATS = 36 * 2 * Q_TB * 4;   // V of one chunk: [xi 36][kk 2][tile 32][s 4] (channel c = 2 s + kk) = 36 KB
 constexpr int Q_HR = 18, Q_HC = 34;            // halo rows / columns of the workgroup's input patch
-constexpr int Q_RS = 12;                       // floats per halo pixel in LDS (8 channels + 4: 16-byte aligned rows, 2-way read conflicts)
-constexpr int QRAW_FLOATS = Q_HR * Q_HC * Q_RS;
+// raw halo of one chunk in LDS: 16-byte slots [row 18][f 68], f = QF_BASE[x & 3] + (x >> 2) * 2 + half (x = halo column, half = channels 0-3 / 4-7):
+// the fill role reads 8 tiles (x step 4) x 2 halves per instruction = 16 consecutive slots, every bank once.  The slots are written by LDS-DMA
+// (lane-linear: instruction q, lane l -> slot q * 64 + l), 20 instructions per chunk, the last one padded with out-of-range lanes.
+constexpr int QRAW_SLOTS = Q_HR * 68;
+constexpr int QRAW_DMA = (QRAW_SLOTS + 63) / 64;
+constexpr int QRAW_FLOATS = QRAW_DMA * 64 * 4;
+__host__ __device__ constexpr int qf_base(int xr) { return xr == 0 ? 0 : xr == 1 ? 18 : xr == 2 ? 36 : 52; }
+constexpr unsigned Q_OOB = 0x7fffff00u;        // beyond any num_records: the buffer load returns 0 = the zero padding of the convolution
 constexpr int Q_TS = 36;                       // floats per (j, r, tile) row of the exchange buffer
 constexpr int QX_FLOATS = 6 * 4 * Q_TB * Q_TS; // one channel half: 110,592 B
 constexpr int QU_CHUNK = 12 * 6 * 256;         // packed U floats per (group, chunk): [wave 12][i 6][lane 64][e 4]
@@ -72,37 +78,35 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
     const int by = b % a.nty;
     const int nb = b / a.nty;
 
-    // ---- loader role: the 18 x 34 x 8-channel halo as 1224 16-byte pieces, one or two per thread (zero padding applied on the way into LDS)
-    const float* inimg = (const float*)a.in.ptr + ((int64_t)nb * a.h * a.w) * a.in.cstride + a.in.coff;
-    int roff[2], rdst[2];
-    bool rok[2];
+    // ---- loader role (waves 0-3, one per SIMD): the 18 x 34 x 8-channel halo of a chunk as 1224 16-byte pieces, five LDS-DMA instructions per
+    // wave.  Only these four waves have the halo's memory latency in their (in-order) vmcnt queue in front of the weight prefetches; with the
+    // loads spread over all twelve waves every wave stalled on it once per chunk at the same point and the MFMA pipe drained (-20 %).
+    const int img_bytes = a.h * a.w * a.in.cstride * 4;
+    const __amdgpu_buffer_rsrc_t in_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * img_bytes + a.in.coff * 4), 0, (unsigned)img_bytes, 0x00020000);
+    unsigned dmaoff[5];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int piece = tid + j * Q_THREADS;
-        const int pix = min(piece, Q_HR * Q_HC * 2 - 1) >> 1, half = piece & 1;
-        const int hy = pix / Q_HC, hx = pix - hy * Q_HC;
+    for (int k = 0; k < 5; ++k) {
+        const int slot = ((wv & 3) * 5 + k) * 64 + l;
+        const int hy = slot / 68, f = slot - hy * 68;
+        const int xr = f < 18 ? 0 : f < 36 ? 1 : f < 52 ? 2 : 3;
+        const int r = f - qf_base(xr);
+        const int hx = (r >> 1) * 4 + xr, half = r & 1;
         const int y = by * 16 - 1 + hy, x = bx * 32 - 1 + hx;
-        rok[j] = y >= 0 && y < a.h && x >= 0 && x < a.w;
-        roff[j] = (min(max(y, 0), a.h - 1) * a.w + min(max(x, 0), a.w - 1)) * a.in.cstride + half * 4;
-        rdst[j] = pix * Q_RS + half * 4;
+        const bool ok = slot < QRAW_SLOTS && y >= 0 && y < a.h && x >= 0 && x < a.w;
+        dmaoff[k] = ok ? (unsigned)(((y * a.w + x) * a.in.cstride + half * 4) * 4) : Q_OOB;
     }
-    const bool second = tid < Q_HR * Q_HC * 2 - Q_THREADS;
-    f32x4 rawreg[2];
-    auto issue_in = [&](int ch) {                // ch may run past the last chunk (clamped: a redundant load instead of a branch)
-        const float* src = inimg + min(ch, a.nchunks - 1) * Q_CK;
-        rawreg[0] = *(const f32x4*)(src + roff[0]);
-        rawreg[1] = *(const f32x4*)(src + roff[1]);
-    };
-    auto put_raw = [&](float* rb) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        *(f32x4*)(rb + rdst[0]) = rok[0] ? rawreg[0] : z;
-        if (second) *(f32x4*)(rb + rdst[1]) = rok[1] ? rawreg[1] : z;
+    auto issue_in = [&](int ch, float* rb) {     // wave-uniform: only called by waves 0-3, ch < nchunks
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(rb + ((wv & 3) * 5 + k) * 256), 16, dmaoff[k],
+                                                     ch * (Q_CK * 4), 0, 0);
     };
 
     // ---- fill role: (tile ft, channel fc) of the chunk, rows fi and fi + 3 of its 6 x 6 transform (fi is uniform per wave) -------------------
     const int fc = tid & 7, ft = (tid >> 3) & 31;
     const int fi = __builtin_amdgcn_readfirstlane(tid >> 8);
-    const int rsrc = (((ft >> 3) * 4) * Q_HC + (ft & 7) * 4) * Q_RS + fc;            // top-left value of this thread's patch in a raw buffer
+    const int rsrc = (((ft >> 3) * 4) * 68 + (ft & 7) * 2 + (fc >> 2)) * 4 + (fc & 3);   // top-left value of this thread's patch in a raw buffer
     const int vdst = (((fc & 1) * Q_TB) + ft) * 4 + (fc >> 1);                       // + xi * 256 floats within a stage
     // the two B^T rows of this wave as scalars (fi is wave uniform): one FMA chain per row and column, no branches in the K loop (a `switch` on
     // the row index cost 13 scalar branches per chunk and broke the loop body into basic blocks the scheduler could not interleave with the MFMAs)
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
     auto fill_col = [&](const float* rb, int col) {      // column `col` of the patch -> entry `col` of the two B^T d rows
         float d[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = rb[rsrc + (k * Q_HC + col) * Q_RS];
+        for (int k = 0; k < 6; ++k) d[k] = rb[rsrc + (k * 68 + qf_base(col & 3) + (col >> 2) * 2) * 4];
         float xa = ca[0] * d[0], xb = cb[0] * d[0];
 #pragma unroll
         for (int k = 1; k < 6; ++k) {
@@ -148,17 +152,18 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    issue_in(0);
+    const bool loader = wv < 4;
+    if (loader) {
+        issue_in(0, rawb);
+        if (a.nchunks > 1) issue_in(1, rawb + QRAW_FLOATS);
+    }
     ureg[0] = *(const f32x4*)(ub);
     ureg[1] = *(const f32x4*)(ub + 256);
-    put_raw(rawb);
-    issue_in(1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int c = 0; c < 6; ++c) fill_col(rawb, c);
     fill_rows(vst);
-    put_raw(rawb + QRAW_FLOATS);
-    issue_in(2);
     __syncthreads();
     for (int ch = 0; ch < a.nchunks; ++ch) {
         const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
@@ -183,12 +188,13 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                 fill_row_out(nst, 2 * (i - 3));
                 fill_row_out(nst, 2 * (i - 3) + 1);
             }
-            if (i == 2) {
-                put_raw(rawb + (ch & 1) * QRAW_FLOATS);   // chunk ch + 2; this buffer's previous content (chunk ch) was consumed an iteration ago
-                issue_in(ch + 3);
-            }
+            // chunk ch + 2 -> the raw buffer whose previous content (chunk ch) was consumed an iteration ago; a whole chunk of lead
+            if (i == 0 && loader && ch + 2 < a.nchunks) issue_in(ch + 2, rawb + (ch & 1) * QRAW_FLOATS);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the DMA of this iteration has landed when at most the two weight prefetches issued behind it (positions 0 and 1 of the next chunk) are
+        // still in flight (loads retire in order)
+        if (loader) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -319,8 +325,8 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3_winograd43_f32: wpacked must be 16-byte aligned");
     auto al = [](const tr_view& v) { return !v.ptr || (v.cstride % 4 == 0 && v.coff % 4 == 0 && ((uintptr_t)v.ptr) % 16 == 0); };
     TR_REQUIRE(al(d->in) && al(d->out) && al(d->mask), TR_EALIGN, "tr_conv3x3_winograd43_f32: views must allow aligned 4-channel access");
-    TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride < (int64_t)0x7fffffff, TR_EUNSUPPORTED,
-               "tr_conv3x3_winograd43_f32: one image of the input must stay below 2^31 elements");
+    TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride * 4 < (int64_t)Q_OOB, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: one image of the input must stay below 2 GB (32-bit buffer offsets)");
     Wino43Args a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
     a.act = d->act; a.mask_slope = d->mask_slope;

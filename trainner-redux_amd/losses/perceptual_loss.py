@@ -329,6 +329,11 @@ class VGG(nn.Module):
             if k == 0:
                 # conv1_1 ran on a replicate-padded image: its input gradient is the 'full' correlation on the padded domain
                 # (MFMA conv, 64 -> 3 channels), folded back onto the image border, scaled by 1/std, added into NCHW grad
+                # fp32 head, 64 -> 3: the tiled VALU kernel reads g once and writes the image gradient directly
+                if g.dtype == torch.float32 and m.cout == 64 and m.cin == 3 and not os.environ.get("TRAINNER_NO_STEM"):
+                    ops.conv3x3_dgrad_image(V(g), m.weight.data, n, hh, ww, grad, pad_mode=L.PAD_REPLICATE, ch_scale=[1.0 / s for s in IMAGENET_STD],
+                                            accumulate=not first)
+                    break
                 ops.conv3x3(n=n, h=hh + 2, w=ww + 2, cin=m.cout, cout=m.cin, compute=cd, inp=V(g), out=V(ws["gp"]), wpacked=pk[name][1],
                             in_mode=L.IN_FULL)
                 ops.fold_replicate_nchw(V(ws["gp"]), grad, ch_scale=[1.0 / s for s in IMAGENET_STD], accumulate=not first)
