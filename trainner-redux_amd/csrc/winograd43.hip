@@ -17,6 +17,9 @@
 //     Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).
 #include "common.h"
 #include <stdlib.h>
+#ifndef TR_W43_ABL
+#define TR_W43_ABL 0     // timing experiments: 1 = no MFMAs, 2 = no fill (results are wrong)
+#endif
 
 namespace {
 
@@ -40,7 +43,8 @@ constexpr unsigned Q_OOB = 0x7fffff00u;        // beyond any num_records: the bu
 constexpr int Q_TS = 36;                       // floats per (j, r, tile) row of the exchange buffer
 constexpr int QX_FLOATS = 6 * 4 * Q_TB * Q_TS; // one channel half: 110,592 B
 constexpr int QU_CHUNK = 12 * 6 * 256;         // packed U floats per (group, chunk): [wave 12][i 6][lane 64][e 4]
-constexpr int Q_SMEM = (2 * QV_FLOATS + 2 * QRAW_FLOATS) * 4;
+constexpr int Q_NRAW = 3;                      // raw halo buffers: the DMA of chunk ch + Q_NRAW is issued while chunk ch is multiplied (3 or 4)
+constexpr int Q_SMEM = (2 * QV_FLOATS + Q_NRAW * QRAW_FLOATS) * 4;
 static_assert(QX_FLOATS * 4 <= Q_SMEM && Q_SMEM <= 160 * 1024, "LDS budget");
 
 struct Wino43Args {
@@ -51,27 +55,48 @@ struct Wino43Args {
     const float* u;
     const float* bias;
     int nty, ntx, nchunks, nkg;
+    long long* stamps;     // diagnostics (builds with -DTR_W43_STAMPS only)
 };
 
-// one row of B^T d for the rows of the transform matrix B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-__device__ __forceinline__ float bt_row(int i, const float (&d)[6]) {
-    switch (i) {
-        case 0: return 4.f * d[0] - 5.f * d[2] + d[4];
-        case 1: return -4.f * (d[1] + d[2]) + d[3] + d[4];
-        case 2: return 4.f * (d[1] - d[2]) - d[3] + d[4];
-        case 3: return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-        case 4: return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-        default: return 4.f * d[1] - 5.f * d[3] + d[5];
+// diagnostics: wave-uniform time stamps (s_memtime) of waves 0 (a loader) and 4 into a.stamps[workgroup][role][64], workgroups below 1024
+#ifdef TR_W43_STAMPS
+#define Q_STAMP()                                                                                                          \
+    if (a.stamps && l == 0 && (wv == 0 || wv == 4) && n_stamp < 64 && blockIdx.x < 1024)                                       \
+        a.stamps[((int64_t)blockIdx.x * 2 + (wv >> 2)) * 64 + n_stamp++] = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define Q_STAMP()
+#endif
+
+// B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] applied to a 6-vector, two rows at a time in the
+// pairing that shares subexpressions: P = 0 -> rows (0, 5), 1 -> rows (1, 2), 2 -> rows (3, 4); 4 / 6 / 4 operations per pair.
+template <int P>
+__device__ __forceinline__ void bt_pair(const float (&d)[6], float& ra, float& rb) {
+    if constexpr (P == 0) {
+        ra = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+        rb = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+    } else if constexpr (P == 1) {
+        ra = fmaf(-4.f, d[1] + d[2], d[4] + d[3]);
+        rb = fmaf(4.f, d[1] - d[2], d[4] - d[3]);
+    } else {
+        const float u = d[3] - d[1], v = d[4] - d[2];
+        ra = fmaf(2.f, u, v);
+        rb = fmaf(-2.f, u, v);
     }
 }
+__host__ __device__ constexpr int bt_row_a(int p) { return p == 0 ? 0 : p == 1 ? 1 : 3; }
+__host__ __device__ constexpr int bt_row_b(int p) { return p == 0 ? 5 : p == 1 ? 2 : 4; }
+template <int V> struct QInt { static constexpr int value = V; };
 
 __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vst = (float*)smem;                       // two V stages
-    float* rawb = vst + 2 * QV_FLOATS;               // two raw halo buffers
+    float* rawb = vst + 2 * QV_FLOATS;               // Q_NRAW raw halo buffers
     const int tid = threadIdx.x;
     const int l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = l & 31, lh = l >> 5;
     const int wj = wv % 6, wkh = wv / 6;
+    int n_stamp = 0;
+    (void)n_stamp;
+    Q_STAMP()
     int b = blockIdx.x;
     const int kg = b % a.nkg; b /= a.nkg;          // output-channel group fastest: neighbours in the grid share the input patch in L2
     const int bx = b % a.ntx; b /= a.ntx;
@@ -103,45 +128,12 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                                                      ch * (Q_CK * 4), 0, 0);
     };
 
-    // ---- fill role: (tile ft, channel fc) of the chunk, rows fi and fi + 3 of its 6 x 6 transform (fi is uniform per wave) -------------------
+    // ---- fill role: (tile ft, channel fc) of the chunk, one row pair of its 6 x 6 transform B^T d B (pair fp is uniform per wave and a
+    // compile-time constant of the K loop below: the loop exists three times and a wave enters its own copy once) -------------------------------
     const int fc = tid & 7, ft = (tid >> 3) & 31;
-    const int fi = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const int fp = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int rsrc = (((ft >> 3) * 4) * 68 + (ft & 7) * 2 + (fc >> 2)) * 4 + (fc & 3);   // top-left value of this thread's patch in a raw buffer
     const int vdst = (((fc & 1) * Q_TB) + ft) * 4 + (fc >> 1);                       // + xi * 256 floats within a stage
-    // the two B^T rows of this wave as scalars (fi is wave uniform): one FMA chain per row and column, no branches in the K loop (a `switch` on
-    // the row index cost 13 scalar branches per chunk and broke the loop body into basic blocks the scheduler could not interleave with the MFMAs)
-    float ca[6], cb[6];
-    {
-        const float BT[6][6] = {{4.f, 0.f, -5.f, 0.f, 1.f, 0.f}, {0.f, -4.f, -4.f, 1.f, 1.f, 0.f}, {0.f, 4.f, -4.f, -1.f, 1.f, 0.f},
-                                {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, 4.f, 0.f, -5.f, 0.f, 1.f}};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            ca[k] = fi == 0 ? BT[0][k] : fi == 1 ? BT[1][k] : BT[2][k];
-            cb[k] = fi == 0 ? BT[3][k] : fi == 1 ? BT[4][k] : BT[5][k];
-        }
-    }
-    float ta[6], tb[6];
-    auto fill_col = [&](const float* rb, int col) {      // column `col` of the patch -> entry `col` of the two B^T d rows
-        float d[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = rb[rsrc + (k * 68 + qf_base(col & 3) + (col >> 2) * 2) * 4];
-        float xa = ca[0] * d[0], xb = cb[0] * d[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) {
-            xa += ca[k] * d[k];
-            xb += cb[k] * d[k];
-        }
-        ta[col] = xa;
-        tb[col] = xb;
-    };
-    auto fill_row_out = [&](float* st, int j) {          // (B^T d) B: output column j of the two rows, into the stage
-        st[vdst + (fi * 6 + j) * 256] = bt_row(j, ta);   // V[i][j] = sum_l t[l] B^T[j][l]
-        st[vdst + ((fi + 3) * 6 + j) * 256] = bt_row(j, tb);
-    };
-    auto fill_rows = [&](float* st) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) fill_row_out(st, j);
-    };
 
     // ---- MFMA role ---------------------------------------------------------------------------------------------------------------------------
     const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256) + l * 4;      // + chunk * QU_CHUNK + i * 256
@@ -153,51 +145,120 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     const bool loader = wv < 4;
-    if (loader) {
-        issue_in(0, rawb);
-        if (a.nchunks > 1) issue_in(1, rawb + QRAW_FLOATS);
-    }
+    const int npre = min(a.nchunks, Q_NRAW);         // halo chunks requested up front
+    if (loader)
+        for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
     ureg[0] = *(const f32x4*)(ub);
     ureg[1] = *(const f32x4*)(ub + 256);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+
+    auto k_loop = [&](auto fp_c) {
+        constexpr int FP = decltype(fp_c)::value;
+        constexpr int RA = bt_row_a(FP), RB = bt_row_b(FP);
+        float ta[6], tb[6];
+        auto fill_col = [&](const float* rb, int col) {      // column `col` of the patch -> entry `col` of the two B^T d rows
+            float d[6];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) fill_col(rawb, c);
-    fill_rows(vst);
-    __syncthreads();
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
-        float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
-        const float* rb = rawb + ((ch + 1) & 1) * QRAW_FLOATS;
-        const float* uc = ub + (int64_t)ch * QU_CHUNK;
-        const float* un = ub + (int64_t)min(ch + 1, a.nchunks - 1) * QU_CHUNK;
-        f32x4 bv[2];
-        bv[0] = *(const f32x4*)(vl + wj * 256);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            if (i + 1 < 6) bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
-            // weights two positions ahead (positions 4 and 5 request positions 0 and 1 of the next chunk)
-            ureg[(i + 2) % 3] = i + 2 < 6 ? *(const f32x4*)(uc + (i + 2) * 256) : *(const f32x4*)(un + (i + 2 - 6) * 256);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i % 3][e], bv[i & 1][e], acc[i], 0, 0, 0);
-            // the next stage's fill rides behind the MFMAs: two patch columns behind each of positions 0-2, two output columns behind each of 3-5
-            if (i < 3) {
-                fill_col(rb, 2 * i);
-                fill_col(rb, 2 * i + 1);
-            } else {
-                fill_row_out(nst, 2 * (i - 3));
-                fill_row_out(nst, 2 * (i - 3) + 1);
-            }
-            // chunk ch + 2 -> the raw buffer whose previous content (chunk ch) was consumed an iteration ago; a whole chunk of lead
-            if (i == 0 && loader && ch + 2 < a.nchunks) issue_in(ch + 2, rawb + (ch & 1) * QRAW_FLOATS);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int k = (FP == 0 ? 0 : 1); k < (FP == 0 ? 6 : 5); ++k) d[k] = rb[rsrc + (k * 68 + qf_base(col & 3) + (col >> 2) * 2) * 4];
+            if (FP != 0) d[0] = d[5] = 0.f;                  // rows 1-4 of B^T do not touch d0 / d5
+            bt_pair<FP>(d, ta[col], tb[col]);
+        };
+        auto fill_out = [&](float* st, int pair) {           // (B^T d) B: the output-column pair of both rows, into the stage
+            const int ja = bt_row_a(pair), jb = bt_row_b(pair);
+            float oa, ob;
+            if (pair == 0) bt_pair<0>(ta, oa, ob); else if (pair == 1) bt_pair<1>(ta, oa, ob); else bt_pair<2>(ta, oa, ob);
+            st[vdst + (RA * 6 + ja) * 256] = oa;
+            st[vdst + (RA * 6 + jb) * 256] = ob;
+            if (pair == 0) bt_pair<0>(tb, oa, ob); else if (pair == 1) bt_pair<1>(tb, oa, ob); else bt_pair<2>(tb, oa, ob);
+            st[vdst + (RB * 6 + ja) * 256] = oa;
+            st[vdst + (RB * 6 + jb) * 256] = ob;
+        };
+
+        // halo of chunk 0 landed: everything issued before the (up to) two later halo chunks and the two weight fragments
+        if (loader) {
+            if (npre == 4) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            else if (npre == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (npre == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         }
-        // the DMA of this iteration has landed when at most the two weight prefetches issued behind it (positions 0 and 1 of the next chunk) are
-        // still in flight (loads retire in order)
-        if (loader) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Q_STAMP()
+#pragma unroll
+        for (int c = 0; c < 6; ++c) fill_col(rawb, c);
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) fill_out(vst, pr);
+        if (loader) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the other chunks requested up front (issued together with chunk 0)
+        __syncthreads();
+        Q_STAMP()
+        int rnext = 1;                                       // raw buffer of chunk ch + 1
+        f32x4 bv[2];
+        bv[0] = *(const f32x4*)(vst + (lh * Q_TB + lr) * 4 + wj * 256);
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
+            float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
+            const float* rb = rawb + rnext * QRAW_FLOATS;
+            const int rfree = rnext == 0 ? Q_NRAW - 1 : rnext - 1;                        // buffer of chunk ch: consumed an iteration ago
+            rnext = rnext == Q_NRAW - 1 ? 0 : rnext + 1;
+            const float* uc = ub + (int64_t)ch * QU_CHUNK;
+            const float* un = ub + (int64_t)min(ch + 1, a.nchunks - 1) * QU_CHUNK;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                if (i == 5) {
+                    // The chunk's barrier sits in front of position 5, not behind it: every fill of the next stage is done by position 4, and
+                    // position 5 needs nothing from LDS any more (its B fragment is in registers), so the MFMA pipe has work the moment the
+                    // barrier releases and the first fragment read of the next stage hides behind these four MFMAs.
+                    // Loads retire in order: halo chunk ch + 2 (issued Q_NRAW - 2 iterations ago, or up front) has landed when only the loads
+                    // behind it in the queue are still in flight: 5 weight fragments of its own iteration + (1 + 5 DMA pieces + 5) per later
+                    // iteration, less this iteration's last fragment which is requested after the barrier.
+                    if (loader) {
+                        static_assert(Q_NRAW == 3 || Q_NRAW == 4, "vmcnt bookkeeping below");
+                        if (ch + Q_NRAW < a.nchunks) {
+                            if (Q_NRAW == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    Q_STAMP()
+                    __builtin_amdgcn_s_barrier();
+                    Q_STAMP()
+                    bv[0] = *(const f32x4*)(nst + (lh * Q_TB + lr) * 4 + wj * 256);       // position 0 of the next chunk
+                } else {
+                    bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
+                }
+                // weights two positions ahead (positions 4 and 5 request positions 0 and 1 of the next chunk)
+                ureg[(i + 2) % 3] = i + 2 < 6 ? *(const f32x4*)(uc + (i + 2) * 256) : *(const f32x4*)(un + (i + 2 - 6) * 256);
+#if !(TR_W43_ABL & 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i % 3][e], bv[i & 1][e], acc[i], 0, 0, 0);
+#else
+                acc[i][0] += ureg[i % 3][0] * bv[i & 1][0] + ureg[i % 3][1] * bv[i & 1][1] + ureg[i % 3][2] * bv[i & 1][2] + ureg[i % 3][3] * bv[i & 1][3];
+#endif
+                // the next stage's fill rides behind the MFMAs: three patch columns behind each of positions 0 and 1, one output-column pair
+                // behind each of positions 2-4
+#if !(TR_W43_ABL & 2)
+                if (i < 2) {
+                    fill_col(rb, 3 * i);
+                    fill_col(rb, 3 * i + 1);
+                    fill_col(rb, 3 * i + 2);
+                } else if (i < 5) {
+                    fill_out(nst, i - 2);
+                }
+#endif
+                // chunk ch + Q_NRAW -> the raw buffer whose content (chunk ch) was consumed an iteration ago: two whole chunks of lead (a halo
+                // chunk is 4-5 us away under load: start -> first halo landed = 11-15k ticks in the stamps; one chunk of lead was short of it on
+                // every fourth chunk, the one that opens a new 128-byte line of the pixel records; a fourth buffer measured no further gain)
+                if (i == 0 && loader && ch + Q_NRAW < a.nchunks) issue_in(ch + Q_NRAW, rawb + rfree * QRAW_FLOATS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the exchange buffer of the epilogue aliases the stages: every wave is past its last fragment read
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-    }
+    };
+    if (fp == 0) k_loop(QInt<0>{});
+    else if (fp == 1) k_loop(QInt<1>{});
+    else k_loop(QInt<2>{});
 
     // ---- output transform + epilogue ----------------------------------------------------------------------------------------------------------
     // column fold T[r] = sum_i A^T[r][i] M[i][j], A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], written per 4-register group
@@ -227,7 +288,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                 *(f32x4*)(dst + 3 * Q_TB * Q_TS) = t3;
             }
         }
-        __syncthreads();
+        // raw barriers with an LDS-only wait: __syncthreads() would also drain the global stores of the previous round (vmcnt) in front of it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Q_STAMP()
         if (tid < 512) {
             const int kc = kg * Q_KB + round * 32 + ek4;
             f32x4 bias = {0.f, 0.f, 0.f, 0.f};
@@ -262,7 +326,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                 }
             }
         }
-        __syncthreads();
+        Q_STAMP()
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Q_STAMP()
     }
 }
 
@@ -334,6 +401,7 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     a.u = (const float*)d->wpacked; a.bias = d->bias;
     a.nty = (d->h + 15) / 16; a.ntx = (d->w + 31) / 32;
     a.nchunks = d->cin / Q_CK; a.nkg = d->cout / Q_KB;
+    a.stamps = getenv("TRAINNER_W43_STAMPS") ? (long long*)strtoull(getenv("TRAINNER_W43_STAMPS"), nullptr, 0) : nullptr;
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: grid too large");
     static const hipError_t attr = hipFuncSetAttribute((const void*)winograd43_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
