@@ -55,8 +55,10 @@ def bench():
         U2, U4 = ops.pack_winograd(wt), ops.pack_winograd43(wt)
         f2 = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD, inp=ops.view(x), out=ops.view(out), wpacked=U2, act=L.ACT_RELU)
         f4 = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(x), out=ops.view(out), wpacked=U4, act=L.ACT_RELU)
+        f4m = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(x), out=ops.view(out), wpacked=U4, mask=ops.view(mk), mask_slope=0.0)
+        mk = torch.randn(n, h, w, cout, device=dev)
         res = []
-        for f in (f2, f4):
+        for f in (f2, f4, f4m):
             for _ in range(2): f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -65,7 +67,7 @@ def bench():
             e1.record(); torch.cuda.synchronize()
             res.append(e0.elapsed_time(e1) / 5)
         flops = 2.0 * n * h * w * 9 * cin * cout
-        print(f"n{n} {h}x{w} {cin}->{cout}: F(2,3) {res[0]:7.3f} ms ({flops / res[0] / 1e9:6.1f} TF/s eff)  F(4,3) {res[1]:7.3f} ms ({flops / res[1] / 1e9:6.1f} TF/s eff)  x{res[0] / res[1]:.2f}", flush=True)
+        print(f"n{n} {h}x{w} {cin}->{cout}: F(2,3) {res[0]:7.3f} ms ({flops / res[0] / 1e9:6.1f} TF/s eff)  F(4,3) {res[1]:7.3f} ms ({flops / res[1] / 1e9:6.1f} TF/s eff)  x{res[0] / res[1]:.2f}  masked (dgrad form) {res[2]:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,6 @@
-"""In-kernel phase stamps of the Winograd F(4,3) kernel (needs a build with -DTR_W43_STAMPS): waves 0 (loader) and 4 stamp kernel start, halo landed,
-first V built, [before barrier, after barrier] per chunk, and the epilogue rounds.  Prints median phase durations in s_memtime ticks (10 ns)."""
+"""In-kernel phase stamps of the Winograd F(4,3) kernel (needs a build with -DTR_W43_STAMPS): waves 0 and 4 stamp, per tile of the persistent
+walk, [halo of chunk 0 landed, first V built, (before barrier, after barrier) per chunk, K loop left, epilogue done].  Prints the median
+differences between consecutive stamps over the workgroups, in s_memtime ticks."""
 import os, sys, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
@@ -22,21 +23,15 @@ f(); torch.cuda.synchronize()
 os.environ.pop("TRAINNER_W43_STAMPS")
 s = st.cpu().numpy().reshape(1024, 2, 64)
 nch = cin // 8
+per_tile = 2 + 2 * nch + 2
 for role in (0, 1):
-    rows = []
-    for b in range(1024):
-        c = s[b, role]; c = c[c > 0]
-        if len(c) >= 3 + 2 * min(nch, 28): rows.append(c)
-    k = min(len(r) for r in rows)
-    a = np.stack([r[:k] for r in rows]).astype(np.int64)
+    rows = [s[b, role] for b in range(1024) if (s[b, role] > 0).sum() == 64]
+    a = np.stack(rows).astype(np.int64)
     d = np.median(np.diff(a, axis=1), axis=0).astype(int)
-    tot = np.median(a[:, -1] - a[:, 0])
-    print(f"role {role}: {len(rows)} workgroups, {k} stamps, median total {tot} ticks")
-    print("  start->halo landed:", d[0], " fill V0:", d[1])
-    loop = d[2:2 + 2 * min(nch, 28)]
-    print("  chunk body (to barrier):", loop[0::2].tolist())
-    print("  barrier wait:", loop[1::2].tolist())
-    print("  rest (epilogue):", d[2 + 2 * min(nch, 28):].tolist())
-# concurrency: how many workgroups overlap in time on average
-allst = s[:, 0, :]; t0 = allst[allst > 0].min(); t1 = allst.max()
-print("span of stamped workgroups:", t1 - t0, "ticks")
+    print(f"role {role}: {len(rows)} workgroups with 64 stamps; stamps per tile {per_tile}; start -> first stamp of tile 0: {d[0]}")
+    body = d[1:]
+    for t in range(0, len(body), per_tile):
+        seg = body[t:t + per_tile]
+        if len(seg) < per_tile: break
+        print(f"  tile {t // per_tile}: fill V0 {seg[0]}  chunks (body/barrier) {[(int(seg[1 + 2 * c]), int(seg[2 + 2 * c])) for c in range(min(nch, 12))]}"
+              f"  K-loop exit {seg[1 + 2 * nch]}  epilogue {seg[2 + 2 * nch]}  -> next tile's first stamp {seg[3 + 2 * nch] if len(seg) > 3 + 2 * nch else '-'}")

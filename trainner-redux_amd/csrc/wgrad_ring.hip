@@ -23,6 +23,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <utility>
+#ifndef TR_WGR_ABL
+#define TR_WGR_ABL 0     // timing experiments: 1 = consumers skip their tiles, 2 = loaders issue nothing (results are wrong)
+#endif
 
 namespace {
 
@@ -90,6 +93,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
         const int64_t in_pix_bytes = (int64_t)a.in.cstride * 2, gy_pix_bytes = (int64_t)a.gy.cstride * 2;
         const unsigned in_img = (unsigned)((int64_t)a.hin * a.win * in_pix_bytes), gy_img = (unsigned)((int64_t)a.h * a.w * gy_pix_bytes);
         for (int k = 0; k < nmine; ++k) {
+            if (TR_WGR_ABL & 2) { __builtin_amdgcn_s_barrier(); continue; }
             int t_ = first + k * a.nslots;
             const int x0 = (t_ % a.ntx) * TW; t_ /= a.ntx;
             const int y0 = (t_ % a.nty) * TH;
@@ -167,7 +171,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
 
     for (int k = 0; k < nmine; ++k) {
         __builtin_amdgcn_s_barrier();
-        if (!live) continue;
+        if (!live || (TR_WGR_ABL & 1)) continue;
         // the wave's first tile row goes into the base pointers: every fragment address below is base + immediate
         const char* st = smem + (k & 1) * C::STAGE;
         const char* xb[3] = {st + xo[0] + rbase * (HALO_W * XPIX), st + xo[1] + rbase * (HALO_W * XPIX), st + xo[2] + rbase * (HALO_W * XPIX)};

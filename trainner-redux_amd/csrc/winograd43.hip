@@ -17,6 +17,7 @@
 //     Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #ifndef TR_W43_ABL
 #define TR_W43_ABL 0     // timing experiments: 1 = no MFMAs, 2 = no fill (results are wrong)
 #endif
@@ -25,6 +26,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int Q_TB = 32;                       // tiles per workgroup (4 rows x 8 cols of 4 x 4 output pixels)
 constexpr int Q_KB = 64;                       // output channels per workgroup
@@ -41,11 +43,11 @@ constexpr int QRAW_FLOATS = QRAW_DMA * 64 * 4;
 __host__ __device__ constexpr int qf_base(int xr) { return xr == 0 ? 0 : xr == 1 ? 18 : xr == 2 ? 36 : 52; }
 constexpr unsigned Q_OOB = 0x7fffff00u;        // beyond any num_records: the buffer load returns 0 = the zero padding of the convolution
 constexpr int Q_TS = 36;                       // floats per (j, r, tile) row of the exchange buffer
-constexpr int QX_FLOATS = 6 * 4 * Q_TB * Q_TS; // one channel half: 110,592 B
+constexpr int QX_FLOATS = 6 * 2 * Q_TB * Q_TS; // one exchange round (channel half x row pair): 55,296 B, inside the two V stages
 constexpr int QU_CHUNK = 12 * 6 * 256;         // packed U floats per (group, chunk): [wave 12][i 6][lane 64][e 4]
-constexpr int Q_NRAW = 3;                      // raw halo buffers: the DMA of chunk ch + Q_NRAW is issued while chunk ch is multiplied (3 or 4)
+constexpr int Q_NRAW = 4;                      // raw halo buffers: the DMA of chunk ch + Q_NRAW is issued while chunk ch is multiplied
 constexpr int Q_SMEM = (2 * QV_FLOATS + Q_NRAW * QRAW_FLOATS) * 4;
-static_assert(QX_FLOATS * 4 <= Q_SMEM && Q_SMEM <= 160 * 1024, "LDS budget");
+static_assert(QX_FLOATS <= 2 * QV_FLOATS && Q_SMEM <= 160 * 1024, "LDS budget");
 
 struct Wino43Args {
     int n, h, w, cin, cout;
@@ -87,71 +89,77 @@ __host__ __device__ constexpr int bt_row_a(int p) { return p == 0 ? 0 : p == 1 ?
 __host__ __device__ constexpr int bt_row_b(int p) { return p == 0 ? 5 : p == 1 ? 2 : 4; }
 template <int V> struct QInt { static constexpr int value = V; };
 
+// MASK: the input-gradient form (ReLU-derivative mask on the output).  A template parameter because the two forms spend the epilogue's registers
+// differently: the masked form holds the round's four mask vectors across the exchange barrier, the plain form holds both bias vectors.
+template <bool MASK>
 __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* vst = (float*)smem;                       // two V stages
-    float* rawb = vst + 2 * QV_FLOATS;               // Q_NRAW raw halo buffers
+    float* vst = (float*)smem;                       // two V stages; the exchange rounds of the epilogue alias them
+    float* rawb = vst + 2 * QV_FLOATS;               // Q_NRAW raw halo buffers: the halo stream runs on across tiles and through the epilogue
     const int tid = threadIdx.x;
     const int l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = l & 31, lh = l >> 5;
     const int wj = wv % 6, wkh = wv / 6;
     int n_stamp = 0;
     (void)n_stamp;
     Q_STAMP()
-    int b = blockIdx.x;
-    const int kg = b % a.nkg; b /= a.nkg;          // output-channel group fastest: neighbours in the grid share the input patch in L2
-    const int bx = b % a.ntx; b /= a.ntx;
-    const int by = b % a.nty;
-    const int nb = b / a.nty;
 
-    // ---- loader role (waves 0-3, one per SIMD): the 18 x 34 x 8-channel halo of a chunk as 1224 16-byte pieces, five LDS-DMA instructions per
-    // wave.  Only these four waves have the halo's memory latency in their (in-order) vmcnt queue in front of the weight prefetches; with the
-    // loads spread over all twelve waves every wave stalled on it once per chunk at the same point and the MFMA pipe drained (-20 %).
+    // ---- persistent tile walk: workgroup b takes tiles first + k * grid, output-channel group fastest.  Ids are dealt so that the workgroups of
+    // one XCD (ids equal mod 8 under round-robin placement: speed only) own a run of consecutive tiles: the channel groups of a patch, which read
+    // the same input, and horizontally adjacent patches, whose halos overlap, meet in that XCD's L2.
+    const int G = gridDim.x;
+    const int ntiles = a.n * a.nty * a.ntx * a.nkg;
+    int first = blockIdx.x;
+    if ((G & 7) == 0) first = (first & 7) * (G >> 3) + (first >> 3);
+    auto decode = [&](int t, int& kg, int& bx, int& by, int& nb) {
+        kg = t % a.nkg; t /= a.nkg;
+        bx = t % a.ntx; t /= a.ntx;
+        by = t % a.nty;
+        nb = t / a.nty;
+    };
+
+    // ---- loader role (waves 8-11, one per SIMD; they hold no global loads or stores of the epilogue): the 18 x 34 x 8-channel halo of a chunk as
+    // 1224 16-byte pieces, five LDS-DMA instructions per wave.  Only these four waves have the halo's memory latency in their (in-order) vmcnt
+    // queue in front of the weight prefetches; with the loads spread over all twelve waves every wave stalled on it once per chunk at the same
+    // point and the MFMA pipe drained (-20 %).  The first Q_NRAW chunks of the NEXT tile are requested as soon as this tile's K loop has ended:
+    // they land while its epilogue runs (the exchange rounds stay inside the V stages, the raw buffers are not aliased).
+    const bool loader = wv >= 8;
     const int img_bytes = a.h * a.w * a.in.cstride * 4;
-    const __amdgpu_buffer_rsrc_t in_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * img_bytes + a.in.coff * 4), 0, (unsigned)img_bytes, 0x00020000);
-    unsigned dmaoff[5];
+    const int npre = min(a.nchunks, Q_NRAW);         // halo chunks requested ahead of a tile's K loop
+    __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in.ptr, 0, 0, 0x00020000);
+    unsigned dmaoff[5] = {Q_OOB, Q_OOB, Q_OOB, Q_OOB, Q_OOB};
+    auto dma_tile = [&](int t) {                     // loader waves: piece offsets of tile t
+        int kg, bx, by, nb;
+        decode(t, kg, bx, by, nb);
+        d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * img_bytes + a.in.coff * 4), 0, (unsigned)img_bytes, 0x00020000);
+        int le = l;                                  // opaque copy: the slot arithmetic is recomputed per tile instead of being hoisted out of the
+        asm volatile("" : "+v"(le));                 // tile loop and kept (spilled) across the K loop
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int slot = ((wv & 3) * 5 + k) * 64 + l;
-        const int hy = slot / 68, f = slot - hy * 68;
-        const int xr = f < 18 ? 0 : f < 36 ? 1 : f < 52 ? 2 : 3;
-        const int r = f - qf_base(xr);
-        const int hx = (r >> 1) * 4 + xr, half = r & 1;
-        const int y = by * 16 - 1 + hy, x = bx * 32 - 1 + hx;
-        const bool ok = slot < QRAW_SLOTS && y >= 0 && y < a.h && x >= 0 && x < a.w;
-        dmaoff[k] = ok ? (unsigned)(((y * a.w + x) * a.in.cstride + half * 4) * 4) : Q_OOB;
-    }
-    auto issue_in = [&](int ch, float* rb) {     // wave-uniform: only called by waves 0-3, ch < nchunks
+        for (int k = 0; k < 5; ++k) {
+            const int slot = ((wv & 3) * 5 + k) * 64 + le;
+            const int hy = slot / 68, f = slot - hy * 68;
+            const int xr = f < 18 ? 0 : f < 36 ? 1 : f < 52 ? 2 : 3;
+            const int r = f - qf_base(xr);
+            const int hx = (r >> 1) * 4 + xr, half = r & 1;
+            const int y = by * 16 - 1 + hy, x = bx * 32 - 1 + hx;
+            const bool ok = slot < QRAW_SLOTS && y >= 0 && y < a.h && x >= 0 && x < a.w;
+            dmaoff[k] = ok ? (unsigned)(((y * a.w + x) * a.in.cstride + half * 4) * 4) : Q_OOB;
+        }
+    };
+    auto issue_in = [&](int ch, float* rb) {         // loader waves (wave-uniform), ch < nchunks
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(rb + ((wv & 3) * 5 + k) * 256), 16, dmaoff[k],
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsrc, (__attribute__((address_space(3))) void*)(rb + ((wv & 3) * 5 + k) * 256), 16, dmaoff[k],
                                                      ch * (Q_CK * 4), 0, 0);
     };
 
     // ---- fill role: (tile ft, channel fc) of the chunk, one row pair of its 6 x 6 transform B^T d B (pair fp is uniform per wave and a
-    // compile-time constant of the K loop below: the loop exists three times and a wave enters its own copy once) -------------------------------
+    // compile-time constant of the tile loop below: the loop exists three times and a wave enters its own copy once) ----------------------------
     const int fc = tid & 7, ft = (tid >> 3) & 31;
     const int fp = __builtin_amdgcn_readfirstlane(tid >> 8);
     const int rsrc = (((ft >> 3) * 4) * 68 + (ft & 7) * 2 + (fc >> 2)) * 4 + (fc & 3);   // top-left value of this thread's patch in a raw buffer
     const int vdst = (((fc & 1) * Q_TB) + ft) * 4 + (fc >> 1);                       // + xi * 256 floats within a stage
 
-    // ---- MFMA role ---------------------------------------------------------------------------------------------------------------------------
-    const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256) + l * 4;      // + chunk * QU_CHUNK + i * 256
-    f32x4 ureg[3];                                   // ring: position p lives in ureg[p % 3] and is requested two positions ahead of its MFMAs
-    f32x16 acc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    const bool loader = wv < 4;
-    const int npre = min(a.nchunks, Q_NRAW);         // halo chunks requested up front
-    if (loader)
-        for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
-    ureg[0] = *(const f32x4*)(ub);
-    ureg[1] = *(const f32x4*)(ub + 256);
-
-    auto k_loop = [&](auto fp_c) {
+    auto tile_loop = [&](auto fp_c) {
         constexpr int FP = decltype(fp_c)::value;
         constexpr int RA = bt_row_a(FP), RB = bt_row_b(FP);
         float ta[6], tb[6];
@@ -173,164 +181,238 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
             st[vdst + (RB * 6 + jb) * 256] = ob;
         };
 
-        // halo of chunk 0 landed: everything issued before the (up to) two later halo chunks and the two weight fragments
-        if (loader) {
-            if (npre == 4) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-            else if (npre == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (npre == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        f32x4 ureg[3];                                       // ring: position p lives in ureg[p % 3] and is requested two positions ahead of its MFMAs
+        const int uoff = l * 4;
+        {
+            int kg, bx, by, nb;
+            decode(first, kg, bx, by, nb);
+            const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256);
+            ureg[0] = *(const f32x4*)(ub + uoff);
+            ureg[1] = *(const f32x4*)(ub + 256 + uoff);
+            ureg[2] = *(const f32x4*)(ub + 512 + uoff);
+            asm volatile("" ::: "memory");                   // the two fragments stay in front of the halo requests in the queue, as on later tiles
+            if (loader) {
+                dma_tile(first);
+                for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
+            }
         }
-        __builtin_amdgcn_s_barrier();
-        Q_STAMP()
+        for (int tile = first; tile < ntiles; tile += G) {
+            int kg, bx, by, nb;
+            decode(tile, kg, bx, by, nb);
+            // packed weights of this wave: wave-uniform base (+ chunk * QU_CHUNK + i * 256) + the lane's 4 floats
+            const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256);
+            const float* ubn = ub;                                                                // chunk 0 of the next tile (clamped at the end)
+            if (tile + G < ntiles) ubn = a.u + ((int64_t)((tile + G) % a.nkg) * a.nchunks * 12 + wv) * (6 * 256);
+            f32x16 acc[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) fill_col(rawb, c);
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int pr = 0; pr < 3; ++pr) fill_out(vst, pr);
-        if (loader) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // the other chunks requested up front (issued together with chunk 0)
-        __syncthreads();
-        Q_STAMP()
-        int rnext = 1;                                       // raw buffer of chunk ch + 1
-        f32x4 bv[2];
-        bv[0] = *(const f32x4*)(vst + (lh * Q_TB + lr) * 4 + wj * 256);
-        for (int ch = 0; ch < a.nchunks; ++ch) {
-            const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
-            float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
-            const float* rb = rawb + rnext * QRAW_FLOATS;
-            const int rfree = rnext == 0 ? Q_NRAW - 1 : rnext - 1;                        // buffer of chunk ch: consumed an iteration ago
-            rnext = rnext == Q_NRAW - 1 ? 0 : rnext + 1;
-            const float* uc = ub + (int64_t)ch * QU_CHUNK;
-            const float* un = ub + (int64_t)min(ch + 1, a.nchunks - 1) * QU_CHUNK;
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+            // ---- V of chunk 0.  The queue of a loader wave holds [3 weight fragments, npre halo chunks of 5 pieces] at this point (loads retire
+            // in order): chunk 0 has landed when only the later chunks are in flight
+            if (loader) {
+                if (npre == 4) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                else if (npre == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else if (npre == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            Q_STAMP()
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                if (i == 5) {
-                    // The chunk's barrier sits in front of position 5, not behind it: every fill of the next stage is done by position 4, and
-                    // position 5 needs nothing from LDS any more (its B fragment is in registers), so the MFMA pipe has work the moment the
-                    // barrier releases and the first fragment read of the next stage hides behind these four MFMAs.
-                    // Loads retire in order: halo chunk ch + 2 (issued Q_NRAW - 2 iterations ago, or up front) has landed when only the loads
-                    // behind it in the queue are still in flight: 5 weight fragments of its own iteration + (1 + 5 DMA pieces + 5) per later
-                    // iteration, less this iteration's last fragment which is requested after the barrier.
-                    if (loader) {
-                        static_assert(Q_NRAW == 3 || Q_NRAW == 4, "vmcnt bookkeeping below");
-                        if (ch + Q_NRAW < a.nchunks) {
-                            if (Q_NRAW == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                            else asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            for (int c = 0; c < 6; ++c) fill_col(rawb, c);
+#pragma unroll
+            for (int pr = 0; pr < 3; ++pr) fill_out(vst, pr);
+            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the other chunks requested ahead
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            Q_STAMP()
+            int rnext = 1 % Q_NRAW;                          // raw buffer of chunk ch + 1
+            f32x4 bv[2];
+            bv[0] = *(const f32x4*)(vst + (lh * Q_TB + lr) * 4 + wj * 256);
+            for (int ch = 0; ch < a.nchunks; ++ch) {
+                const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
+                float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
+                const float* rb = rawb + rnext * QRAW_FLOATS;
+                const int rfree = rnext == 0 ? Q_NRAW - 1 : rnext - 1;                        // buffer of chunk ch: consumed an iteration ago
+                rnext = rnext == Q_NRAW - 1 ? 0 : rnext + 1;
+                const float* uc = ub + (int64_t)ch * QU_CHUNK;
+                const float* un = ch + 1 < a.nchunks ? uc + QU_CHUNK : ubn;
+                const bool issued = ch + Q_NRAW < a.nchunks;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    if (i == 5) {
+                        // The chunk's barrier sits in front of position 5, not behind it: every fill of the next stage is done by position 4, and
+                        // position 5 needs nothing from LDS any more (its B fragment is in registers), so the MFMA pipe has work the moment the
+                        // barrier releases and the first fragment read of the next stage hides behind these four MFMAs.
+                        // Loads retire in order: the halo chunk two ahead in the stream (requested Q_NRAW - 2 iterations ago, or up front) has
+                        // landed when only the loads behind it in the queue are still in flight: 5 weight fragments of its own iteration +
+                        // (1 + 5 DMA pieces + 5) per later iteration, less this iteration's last fragment which is requested after the barrier.
+                        if (loader) {
+                            static_assert(Q_NRAW == 4, "vmcnt bookkeeping below");
+                            if (issued) {
+                                asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+                            } else {
+                                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                            }
                         }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        Q_STAMP()
+                        __builtin_amdgcn_s_barrier();
+                        Q_STAMP()
+                        bv[0] = *(const f32x4*)(nst + (lh * Q_TB + lr) * 4 + wj * 256);       // position 0 of the next chunk
+                    } else {
+                        bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    Q_STAMP()
-                    __builtin_amdgcn_s_barrier();
-                    Q_STAMP()
-                    bv[0] = *(const f32x4*)(nst + (lh * Q_TB + lr) * 4 + wj * 256);       // position 0 of the next chunk
-                } else {
-                    bv[(i + 1) & 1] = *(const f32x4*)(vl + ((i + 1) * 6 + wj) * 256);
-                }
-                // weights two positions ahead (positions 4 and 5 request positions 0 and 1 of the next chunk)
-                ureg[(i + 2) % 3] = i + 2 < 6 ? *(const f32x4*)(uc + (i + 2) * 256) : *(const f32x4*)(un + (i + 2 - 6) * 256);
+                    // weights two positions ahead (positions 4 and 5 request positions 0 and 1 of the next chunk, or of the next tile's first).
+                    // Position 2 of a tile's FIRST chunk is already there, requested before the previous tile's epilogue: a finishing wave's loads
+                    // queue behind its output stores (one vmcnt counter, retired in order), so the first fragment requested after the epilogue
+                    // should be needed as late as possible; this way it is position 3, needed three positions into the loop (the acknowledgement
+                    // of the stores takes ~10k ticks, so the tile's first chunk still runs 4-5k ticks long; peeling that chunk to start from C = 0
+                    // and hold positions 3 and 4 in the idle accumulator registers as well cost more in spills than it hid)
+                    if (i == 0) {
+                        if (ch != 0) ureg[2] = *(const f32x4*)(uc + 2 * 256 + uoff);
+                    } else {
+                        ureg[(i + 2) % 3] = i + 2 < 6 ? *(const f32x4*)(uc + (i + 2) * 256 + uoff) : *(const f32x4*)(un + (i + 2 - 6) * 256 + uoff);
+                    }
 #if !(TR_W43_ABL & 1)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i % 3][e], bv[i & 1][e], acc[i], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ureg[i % 3][e], bv[i & 1][e], acc[i], 0, 0, 0);
 #else
-                acc[i][0] += ureg[i % 3][0] * bv[i & 1][0] + ureg[i % 3][1] * bv[i & 1][1] + ureg[i % 3][2] * bv[i & 1][2] + ureg[i % 3][3] * bv[i & 1][3];
+                    acc[i][0] += ureg[i % 3][0] * bv[i & 1][0] + ureg[i % 3][1] * bv[i & 1][1] + ureg[i % 3][2] * bv[i & 1][2] + ureg[i % 3][3] * bv[i & 1][3];
 #endif
-                // the next stage's fill rides behind the MFMAs: three patch columns behind each of positions 0 and 1, one output-column pair
-                // behind each of positions 2-4
+                    // the next stage's fill rides behind the MFMAs: three patch columns behind each of positions 0 and 1, one output-column pair
+                    // behind each of positions 2-4
 #if !(TR_W43_ABL & 2)
-                if (i < 2) {
-                    fill_col(rb, 3 * i);
-                    fill_col(rb, 3 * i + 1);
-                    fill_col(rb, 3 * i + 2);
-                } else if (i < 5) {
-                    fill_out(nst, i - 2);
-                }
+                    // (on a tile's last chunk the fill builds an unused stage from a stale raw buffer: cheaper than branches around it)
+                    if (i < 2) {
+                        fill_col(rb, 3 * i);
+                        fill_col(rb, 3 * i + 1);
+                        fill_col(rb, 3 * i + 2);
+                    } else if (i < 5) {
+                        fill_out(nst, i - 2);
+                    }
 #endif
-                // chunk ch + Q_NRAW -> the raw buffer whose content (chunk ch) was consumed an iteration ago: two whole chunks of lead (a halo
-                // chunk is 4-5 us away under load: start -> first halo landed = 11-15k ticks in the stamps; one chunk of lead was short of it on
-                // every fourth chunk, the one that opens a new 128-byte line of the pixel records; a fourth buffer measured no further gain)
-                if (i == 0 && loader && ch + Q_NRAW < a.nchunks) issue_in(ch + Q_NRAW, rawb + rfree * QRAW_FLOATS);
-                __builtin_amdgcn_sched_barrier(0);
+                    // chunk ch + Q_NRAW goes to the raw buffer whose chunk (the one being multiplied) was consumed an iteration ago: two whole
+                    // chunks of lead (a halo chunk is 4-5 us away under load: start -> first halo landed = 11-15k ticks in the
+                    // stamps; one chunk of lead was short of it on every fourth chunk, the one that opens a new 128-byte line of the pixel
+                    // records; a fourth buffer measured no further gain)
+                    if (i == 0 && loader && issued) issue_in(ch + Q_NRAW, rawb + rfree * QRAW_FLOATS);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-        }
-        // the exchange buffer of the epilogue aliases the stages: every wave is past its last fragment read
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
-    if (fp == 0) k_loop(QInt<0>{});
-    else if (fp == 1) k_loop(QInt<1>{});
-    else k_loop(QInt<2>{});
+            ureg[2] = *(const f32x4*)(ubn + 2 * 256 + uoff);                                     // position 2 of the next tile's first chunk
+            // the exchange rounds below alias the stages: every wave is past its last fragment read (and every raw buffer has been consumed)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            Q_STAMP()
 
-    // ---- output transform + epilogue ----------------------------------------------------------------------------------------------------------
-    // column fold T[r] = sum_i A^T[r][i] M[i][j], A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], written per 4-register group
-    float* tl = (float*)smem;
-    const int ek4 = (tid & 7) * 4, erp = (tid >> 3) & 1, et = tid >> 4;     // finishing role (threads < 512): channel quad, row pair, tile
-    const int ty = et >> 3, tx = et & 7;
-#pragma unroll 1
-    for (int round = 0; round < 2; ++round) {
-        if (wkh == round) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 t0, t1, t2, t3;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a0 = acc[0][q * 4 + e], a1 = acc[1][q * 4 + e], a2 = acc[2][q * 4 + e], a3 = acc[3][q * 4 + e], a4 = acc[4][q * 4 + e],
-                                a5 = acc[5][q * 4 + e];
-                    const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
-                    t0[e] = a0 + s12 + s34;
-                    t1[e] = d12 + 2.f * d34;
-                    t2[e] = s12 + 4.f * s34;
-                    t3[e] = d12 + 8.f * d34 + a5;
-                }
-                float* dst = tl + ((wj * 4) * Q_TB + lr) * Q_TS + q * 8 + lh * 4;
-                *(f32x4*)(dst) = t0;
-                *(f32x4*)(dst + 1 * Q_TB * Q_TS) = t1;
-                *(f32x4*)(dst + 2 * Q_TB * Q_TS) = t2;
-                *(f32x4*)(dst + 3 * Q_TB * Q_TS) = t3;
+            // ---- output transform + epilogue ----------------------------------------------------------------------------------------------
+            // bias of the two channel halves, requested ahead of the rounds that add it (finishing threads: channel quad ek4 = (tid & 7) * 4)
+            f32x4 bias2[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if (!MASK && a.bias && tid < 512) {
+                bias2[0] = *(const f32x4*)(a.bias + kg * Q_KB + (tid & 7) * 4);
+                bias2[1] = *(const f32x4*)(a.bias + kg * Q_KB + 32 + (tid & 7) * 4);
             }
-        }
-        // raw barriers with an LDS-only wait: __syncthreads() would also drain the global stores of the previous round (vmcnt) in front of it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        Q_STAMP()
-        if (tid < 512) {
-            const int kc = kg * Q_KB + round * 32 + ek4;
-            f32x4 bias = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias = *(const f32x4*)(a.bias + kc);
+            // column fold T[r] = sum_i A^T[r][i] M[i][j], A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1], in place: acc[r] <- T[r]
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int r = erp * 2 + rr;
-                const float* tp = tl + (r * Q_TB + et) * Q_TS + ek4;
-                f32x4 T[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) T[j] = *(const f32x4*)(tp + j * 4 * Q_TB * Q_TS);
-                const f32x4 s12 = T[1] + T[2], d12 = T[1] - T[2], s34 = T[3] + T[4], d34 = T[3] - T[4];
-                const f32x4 y[4] = {T[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + T[5]};
-                const int oy = by * 16 + ty * 4 + r;
-                if (oy >= a.h) continue;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int ox = bx * 32 + tx * 4 + s;
-                    if (ox >= a.w) continue;
-                    const int64_t pix = ((int64_t)nb * a.h + oy) * a.w + ox;
-                    f32x4 v = y[s] + bias;
-                    if (a.act == TR_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (a.mask.ptr) {
-                        const f32x4 m = *(const f32x4*)((const float*)a.mask.ptr + pix * a.mask.cstride + a.mask.coff + kc);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= m[e] > 0.f ? 1.f : a.mask_slope;
-                    }
-                    *(f32x4*)((float*)a.out.ptr + pix * a.out.cstride + a.out.coff + kc) = v;
-                }
+            for (int e = 0; e < 16; ++e) {
+                const float a0 = acc[0][e], a1 = acc[1][e], a2 = acc[2][e], a3 = acc[3][e], a4 = acc[4][e], a5 = acc[5][e];
+                const float s12 = a1 + a2, d12 = a1 - a2, s34 = a3 + a4, d34 = a3 - a4;
+                float t0 = a0 + s12 + s34, t1 = d12 + 2.f * d34, t2 = s12 + 4.f * s34, t3 = d12 + 8.f * d34 + a5;
+                // pinned here: left to itself the compiler sinks this arithmetic to the exchange rounds and keeps all six accumulators alive
+                asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                acc[0][e] = t0;
+                acc[1][e] = t1;
+                acc[2][e] = t2;
+                acc[3][e] = t3;
             }
+            // the next tile's first halo chunks land during this tile's epilogue (requested here, behind the fold: a third of the accumulator
+            // registers has just been freed for the offset arithmetic)
+            if (loader && tile + G < ntiles) {
+                dma_tile(tile + G);
+                for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
+            }
+            // four exchange rounds (channel half x row pair) through [j 6][row 2][tile 32][36-float rows] = 54 KB inside the stages, so that the
+            // raw buffers keep the next tile's first halo chunks; then the row fold Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte
+            // stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).  Raw barriers with LDS-only waits: the stores drain behind.
+            float* tl = (float*)smem;
+            // finishing role (threads < 512): channel quad, row of the round's pair, tile.  Stores and mask loads go through buffer resources of
+            // this image: 32-bit offsets, out-of-range rows / columns of partial tiles are dropped by the bounds check (no branches)
+            // (thread-id terms are re-derived behind an opaque copy of tid: hoisted out of the tile loop they would have to live across the K loop,
+            // where every register is taken, and came back from scratch at the latency of a memory access per round)
+            int te = tid;
+            asm volatile("" : "+v"(te));
+            const int ek4 = (te & 7) * 4, erl = (te >> 3) & 1, et = te >> 4;
+            const int elr = te & 31, elh = (te >> 5) & 1;
+            const int out_img = a.h * a.w * a.out.cstride * 4, mask_img = a.h * a.w * a.mask.cstride * 4;
+            const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)a.out.ptr + (int64_t)nb * out_img + (a.out.coff + kg * Q_KB) * 4), 0, (unsigned)out_img, 0x00020000);
+            const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)a.mask.ptr + (int64_t)nb * mask_img + (a.mask.coff + kg * Q_KB) * 4), 0, (unsigned)mask_img, 0x00020000);
+            const int ox0 = bx * 32 + (et & 7) * 4, oy0 = by * 16 + (et >> 3) * 4 + erl;
+#pragma unroll
+            for (int round = 0; round < 4; ++round) {
+                const int rkh = round >> 1, rp = round & 1;
+                // finishing threads request the round's ReLU-derivative mask values first: they arrive while the exchange goes through LDS
+                const int oy = oy0 + rp * 2;
+                u32x4 mu[4];
+                if (MASK && te < 512) {
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const bool ok = oy < a.h && ox0 + sx < a.w;
+                        mu[sx] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, ok ? ((oy * a.w + ox0 + sx) * a.mask.cstride + rkh * 32 + ek4) * 4 : (int)Q_OOB, 0, 0);
+                    }
+                }
+                if (wkh == rkh) {
+#pragma unroll
+                    for (int rl = 0; rl < 2; ++rl)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x16& t = acc[rp * 2 + rl];
+                            const f32x4 v = {t[q * 4], t[q * 4 + 1], t[q * 4 + 2], t[q * 4 + 3]};
+                            *(f32x4*)(tl + ((wj * 2 + rl) * Q_TB + elr) * Q_TS + q * 8 + elh * 4) = v;
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (te < 512) {
+                    const int kc = rkh * 32 + ek4;                    // channel within the workgroup's 64
+                    f32x4 bias = bias2[rkh];
+                    if (MASK && a.bias) bias = *(const f32x4*)(a.bias + kg * Q_KB + kc);
+                    const float* tp = tl + (erl * Q_TB + et) * Q_TS + ek4;
+                    f32x4 T[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) T[j] = *(const f32x4*)(tp + j * 2 * Q_TB * Q_TS);
+                    const f32x4 s12 = T[1] + T[2], d12 = T[1] - T[2], s34 = T[3] + T[4], d34 = T[3] - T[4];
+                    const f32x4 y[4] = {T[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + T[5]};
+#pragma unroll
+                    for (int sx = 0; sx < 4; ++sx) {
+                        const int ox = ox0 + sx;
+                        const bool ok = oy < a.h && ox < a.w;
+                        const int pixi = oy * a.w + ox;
+                        f32x4 v = y[sx] + bias;
+                        if (a.act == TR_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        if (MASK) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= __uint_as_float(mu[sx][e]) > 0.f ? 1.f : a.mask_slope;
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                               out_rsrc, ok ? (pixi * a.out.cstride + kc) * 4 : (int)Q_OOB, 0, 0);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            Q_STAMP()
         }
-        Q_STAMP()
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        Q_STAMP()
-    }
+    };
+    if (fp == 0) tile_loop(QInt<0>{});
+    else if (fp == 1) tile_loop(QInt<1>{});
+    else tile_loop(QInt<2>{});
 }
 
 // U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], for g = w[co][ci] (or, transposed, the
@@ -392,8 +474,9 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3_winograd43_f32: wpacked must be 16-byte aligned");
     auto al = [](const tr_view& v) { return !v.ptr || (v.cstride % 4 == 0 && v.coff % 4 == 0 && ((uintptr_t)v.ptr) % 16 == 0); };
     TR_REQUIRE(al(d->in) && al(d->out) && al(d->mask), TR_EALIGN, "tr_conv3x3_winograd43_f32: views must allow aligned 4-channel access");
-    TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride * 4 < (int64_t)Q_OOB, TR_EUNSUPPORTED,
-               "tr_conv3x3_winograd43_f32: one image of the input must stay below 2 GB (32-bit buffer offsets)");
+    TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride * 4 < (int64_t)Q_OOB && (int64_t)d->h * d->w * d->out.cstride * 4 < (int64_t)Q_OOB &&
+                   (!d->mask.ptr || (int64_t)d->h * d->w * d->mask.cstride * 4 < (int64_t)Q_OOB),
+               TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: one image of the input / output / mask must stay below 2 GB (32-bit buffer offsets)");
     Wino43Args a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
     a.act = d->act; a.mask_slope = d->mask_slope;
@@ -404,8 +487,19 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     a.stamps = getenv("TRAINNER_W43_STAMPS") ? (long long*)strtoull(getenv("TRAINNER_W43_STAMPS"), nullptr, 0) : nullptr;
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: grid too large");
-    static const hipError_t attr = hipFuncSetAttribute((const void*)winograd43_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+    static const hipError_t attr = [] {
+        const hipError_t e0 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+        const hipError_t e1 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+        return e0 != hipSuccess ? e0 : e1;
+    }();
     TR_REQUIRE(attr == hipSuccess, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: the device does not grant %d bytes of LDS per workgroup", Q_SMEM);
-    hipLaunchKernelGGL(winograd43_f32_kernel, dim3((unsigned)nblk), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    static const int ncu = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);          // persistent: one workgroup per CU walks its tiles
+    if (a.mask.ptr) hipLaunchKernelGGL(winograd43_f32_kernel<true>, dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(winograd43_f32_kernel<false>, dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
     return tr::launch_status("tr_conv3x3_winograd43_f32");
 }
