@@ -82,9 +82,9 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const int slot = id % a.nslots; id /= a.nslots;
     const int pc = id % npc;
     const int cg = id / npc;
-    // tile walk: slot s starts at tile first(s) and strides by nslots.  The slots of one XCD (ids equal mod 8 under round-robin placement) start on
-    // a run of consecutive tiles, so that the halo rows / columns shared by neighbouring tiles are fetched once into that XCD's L2 (speed only)
-    const int first = (a.nslots & 7) == 0 ? (slot & 7) * (a.nslots >> 3) + (slot >> 3) : slot;
+    // tile walk: slot s takes tiles s + k * nslots (dealing the slots of one XCD a run of consecutive tiles instead, for halo reuse in its L2,
+    // measured +5-10 % FETCH_SIZE and no change in time: the neighbours in a run are not in step)
+    const int first = slot;
     const int nmine = (a.ntiles - first + a.nslots - 1) / a.nslots;
 
     if (wv >= NCW) {
