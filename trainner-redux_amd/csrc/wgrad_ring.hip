@@ -142,6 +142,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile k has landed (D = 1: it was issued while the consumers worked on tile k - 1)
             __builtin_amdgcn_s_barrier();
         }
+        if (NT == 1) {                                           // the consumers' exchange of the two pixel-row halves (below)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        }
         return;
     }
 
@@ -221,8 +225,32 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
         static_for<NI>(item);
     }
 
-    // partial block of this wave: [slot_eff][chunk][cg][co_local CG][tap 9][ci_local 32]; the two pixel-row halves of the 32-wide form are two slots
-    const int64_t slot_eff = NT == 1 ? (int64_t)slot * 2 + hi : slot;
+    // 32-wide form: the two pixel-row halves of the tile (waves hi = 0 / 1 of an input-channel half) hold partial sums of the SAME block; the upper
+    // half hands its nine accumulators (and bias sums) over through the idle stages, so that a workgroup writes one partial block per chunk, not two
+    // (halves the partial traffic of the launch and of the reduction stage: 33 -> 16 MB written and read back per dense-block conv at batch 16)
+    if (NT == 1) {
+        float* xch = (float*)smem + cih * (9 * 16 * 64 + 64);
+        __builtin_amdgcn_s_barrier();                             // every consumer wave is past its last fragment read
+        if (hi == 1) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) xch[(tap * 16 + reg) * 64 + l] = acc[tap][reg];
+            xch[9 * 16 * 64 + l] = bsum;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (hi == 1) return;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[tap][reg] += xch[(tap * 16 + reg) * 64 + l];
+            asm volatile("" : "+v"(acc[tap]));                    // one accumulator's worth of reads in flight: all 144 at once spill
+        }
+        bsum += xch[9 * 16 * 64 + l];
+    }
+    // partial block of this wave: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
+    const int64_t slot_eff = slot;
     if (do_bias) {
         const float v = bsum + __shfl_xor(bsum, 32, 64);             // the two lane halves hold disjoint pixels of one channel
         if (lh == 0) a.db_partials[(slot_eff * a.ncg + cg) * C::CG + coh * 32 + (l & 31)] = v;
@@ -256,7 +284,7 @@ WgRingPlan wgrad_ring_plan(int n, int h, int w, int cin, int cout) {
     if (target < 1) target = 1;
     p.nslots = p.ntiles < target ? p.ntiles : target;
     if (p.nslots >= 8) p.nslots &= ~7;                       // XCD alignment of the workgroups that walk the same tiles
-    p.slots_eff = p.nslots * (p.cgw == 32 ? 2 : 1);
+    p.slots_eff = p.nslots;
     p.dw_floats = (size_t)p.slots_eff * p.nchunks * p.ncg * p.cgw * 9 * 32;
     p.db_floats = (size_t)p.slots_eff * p.ncg * p.cgw;
     return p;
