@@ -191,6 +191,11 @@ typedef struct tr_wgrad3x3_desc {
 size_t tr_wgrad3x3_workspace_bytes(int n, int h, int w, int cin, int cout);
 size_t tr_wgrad_workspace_bytes(int n, int h, int w, int cin, int cout, int ksize);
 int    tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d);
+/* The weight / bias gradients of several 3x3 convs that read channel slices of ONE input buffer and ONE output-gradient buffer (RRDBNet's
+ * ResidualDenseBlock_5C, spandrel ESRGAN: conv k sees cat(x, x1..x_{k-1}); autograd's five conv_backward_weight calls of sr_model.py:681) in one
+ * launch, so that the shared bytes are fetched once; every descriptor carries its own dw / db / partials.  Same results, bit for bit per conv,
+ * as ndesc calls of tr_wgrad3x3 with the same partial slot count; falls back to exactly those calls for sets it cannot fuse. */
+int    tr_wgrad3x3_multi(void* stream, const tr_wgrad3x3_desc* descs, int ndesc);
 
 /* ---- layout / pointwise ----------------------------------------------------------------------
  * NCHW fp32 image batch (the DataFeed contract, utils/types.py:10-17) -> NHWC view, optionally

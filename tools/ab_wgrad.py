@@ -77,3 +77,47 @@ if __name__ == "__main__":
     if what in ("check", "all"):
         if check() and what == "all": sys.exit(1)
     if what in ("bench", "all"): bench()
+
+
+def multi():
+    """The five weight gradients of a dense block (channel prefixes of one 192-channel x buffer, slices of one 192-channel gradient buffer):
+    one fused launch (tr_wgrad3x3_multi) against five separate ones -- agreement, then time per block."""
+    nf, gc = 64, 32
+    for (n, h, w) in [(2, 40, 72), (16, 256, 256)]:
+        xb = torch.randn(n, h, w, nf + 4 * gc, device=dev).bfloat16()
+        g = (torch.randn(n, h, w, nf + 4 * gc, device=dev) / 16).bfloat16()
+        shapes = [(nf + gc * (c - 1), gc if c < 5 else nf, 0 if c == 5 else nf + gc * (4 - c)) for c in range(1, 6)]
+        need = max(ops.wgrad_workspace_bytes(n, h, w, ci, co) for ci, co, _ in shapes)
+        wss = [torch.empty(need // 4 + 16, dtype=torch.float32, device=dev) for _ in range(5)]
+
+        def run(fused):
+            os.environ["TRAINNER_WGRAD_IMPL"] = "ring"
+            os.environ["TRAINNER_WGRAD_MULTI"] = "1" if fused else "0"
+            dws = [torch.full((co, ci, 3, 3), 0.5, device=dev) for ci, co, _ in shapes]
+            dbs = [torch.full((co,), 0.25, device=dev) for ci, co, _ in shapes]
+            convs = [dict(cin=ci, cout=co, inp=ops.view(xb, 0, ci), gy=ops.view(g, go, co), dw=dws[k], db=dbs[k], workspace=wss[k]) for k, (ci, co, go) in enumerate(shapes)]
+            f = lambda: ops.wgrad3x3_multi(convs, n=n, h=h, w=w, compute=L.BF16, accumulate=True)
+            f(); torch.cuda.synchronize()
+            return dws, dbs, f
+        d0, b0, f0 = run(False)
+        d1, b1, f1 = run(True)
+        bad = 0
+        for k in range(5):
+            ew = ((d1[k] - d0[k]).double().norm() / (d0[k] - 0.5).double().norm()).item()
+            eb = ((b1[k] - b0[k]).double().norm() / (b0[k] - 0.25).double().norm()).item()
+            bad += not (ew < 2e-6 and eb < 2e-6)
+            print(f"n{n} {h}x{w} conv{k + 1} {shapes[k][0]}->{shapes[k][1]}: dw rel {ew:.2e} db rel {eb:.2e}")
+        print("multi check mismatches:", bad)
+        if n * h * w < 256 * 512: continue
+        for name, fused in (("separate", False), ("fused", True)):
+            _, _, f = run(fused)
+            for _ in range(2): f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): f()
+            e1.record(); torch.cuda.synchronize()
+            print(f"  {name}: {e0.elapsed_time(e1) / 10:.3f} ms per dense block (5 wgrads + reductions)")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "multi": multi()

@@ -121,6 +121,7 @@ SYMBOLS = {
     "tr_wgrad3x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_wgrad3x3": (C.c_int, [C.c_void_p, C.POINTER(Wgrad3x3Desc)]),
+    "tr_wgrad3x3_multi": (C.c_int, [C.c_void_p, C.POINTER(Wgrad3x3Desc), C.c_int]),
     "tr_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, View, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "tr_nhwc_to_nchw": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_nhwc_to_nchw_scaled": (C.c_int, [C.c_void_p, View, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int]),

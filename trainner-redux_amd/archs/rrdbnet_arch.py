@@ -220,6 +220,8 @@ class RRDBNet(FlatParamModule):
         for (hh, ww, cin, cout) in shapes:
             need = max(need, ops.wgrad_workspace_bytes(n, hh, ww, cin, cout))
         ws.wg = torch.empty(need // 4 + 16, dtype=torch.float32, device=dev)
+        # one more workspace per conv of a dense block: its five weight gradients go out as one launch (ops.wgrad3x3_multi)
+        ws.wg5 = [ws.wg] + [torch.empty(need // 4 + 16, dtype=torch.float32, device=dev) for _ in range(4)]
 
     # ------------------------------------------------------------------ forward ---------------------
     def forward_hip(self, x: torch.Tensor, train: bool | None = None) -> torch.Tensor:
@@ -371,10 +373,14 @@ class RRDBNet(FlatParamModule):
                     if i > 0:
                         kw.update(out2=V(G[cur ^ 1], 0, nf), out2_scale=RES * RES)
                 ops.conv3x3(h=h, w=w, cin=nf + 4 * gc, cout=nf, inp=V(g), out=V(g_next), wpacked=bw[0], **kw, **K)
+                # the five weight gradients of the block read channel prefixes of xb and slices of g: one launch (tr_wgrad3x3_multi)
+                convs = []
                 for c in range(1, 6):
                     cv = getattr(getattr(rdb, f"conv{c}"), "0")
                     goff = 0 if c == 5 else nf + gc * (4 - c)
-                    wgrad(cv, V(xb, 0, cv.cin), V(g, goff, cv.cout), h, w)
+                    convs.append(dict(cin=cv.cin, cout=cv.cout, inp=V(xb, 0, cv.cin), gy=V(g, goff, cv.cout), dw=cv.weight.grad, db=cv.bias.grad,
+                                      workspace=ws.wg5[c - 1]))
+                ops.wgrad3x3_multi(convs, n=n, h=h, w=w, compute=cd, accumulate=True)
                 g_y = g_next
                 cur ^= 1
             g_z = g_y

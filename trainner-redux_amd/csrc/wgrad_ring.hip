@@ -70,18 +70,17 @@ struct WCfg {
 #define TR_TRRD(PTR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(PTR))
 
 template <int CT, int NT>
-__global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, int npc) {
+__global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, WgRoles roles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef WCfg<NT> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int l = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // workgroup id = slot + nslots * (pair-chunk + npc * cg): with nslots a multiple of 8 the workgroups that walk the SAME tiles share an XCD's L2
-    int id = blockIdx.x;
-    const int slot = id % a.nslots; id /= a.nslots;
-    const int pc = id % npc;
-    const int cg = id / npc;
+    // workgroup id = slot + nslots * role (wgrad_args.h): with nslots a multiple of 8 the workgroups that walk the SAME tiles share an XCD's L2
+    const int slot = blockIdx.x % a.nslots;
+    const WgRole& R = roles.r[blockIdx.x / a.nslots];
+    const int pc = R.pc, cg = R.cg;
     // tile walk: slot s takes tiles s + k * nslots (dealing the slots of one XCD a run of consecutive tiles instead, for halo reuse in its L2,
     // measured +5-10 % FETCH_SIZE and no change in time: the neighbours in a run are not in step)
     const int first = slot;
@@ -119,7 +118,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
                     ok = true;
                 }
                 const int c0 = pc * 64 + s * 8;
-                ok = ok & (c0 + 8 <= a.in.c);
+                ok = ok & (c0 + 8 <= R.in_c);
                 const unsigned off = (unsigned)(((int64_t)(oy >> a.up) * a.win + (ox >> a.up)) * in_pix_bytes + (int64_t)(a.in.coff + c0) * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (__attribute__((address_space(3))) void*)(st + p0 * 16), 16, ok ? off : OOB, 0, 0, 0);
             }
@@ -135,8 +134,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
                 if (NT == 2) s ^= ((col >> 1) & 1) << 2;
                 const int oy = y0 + (gp >> 5), ox = x0 + col;
                 const int c0 = cg * C::CG + s * 8;
-                const bool ok = (oy < a.h) & (ox < a.w) & (c0 + 8 <= a.gy.c);
-                const unsigned off = (unsigned)(((int64_t)oy * a.w + ox) * gy_pix_bytes + (int64_t)(a.gy.coff + c0) * 2);
+                const bool ok = (oy < a.h) & (ox < a.w) & (c0 + 8 <= R.gy_c);
+                const unsigned off = (unsigned)(((int64_t)oy * a.w + ox) * gy_pix_bytes + (int64_t)(R.gy_coff + c0) * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(gy_rsrc, (__attribute__((address_space(3))) void*)(st + X_BYTES + p0 * 16), 16, ok ? off : OOB, 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile k has landed (D = 1: it was issued while the consumers worked on tile k - 1)
@@ -153,7 +152,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const int cih = wv & 1;                       // input-channel half of the workgroup's 64
     const int hi = wv >> 1;                       // NT 1: pixel-row half of the tile ; NT 2: output-channel half
     const int chunk = pc * 2 + cih;               // 32-channel chunk of the partial layout
-    const bool live = chunk < a.nchunks;          // a 32-channel tail (cin = 96, 160): the other half of the last pair has nothing to do
+    const bool live = chunk < R.nchunks;          // a 32-channel tail (cin = 96, 160): the other half of the last pair has nothing to do
     const int lh = l >> 5, li = l & 15, q = li >> 2, p = li & 3;
     const int i0 = ((l >> 4) & 1) * 16;
     const int rbase = NT == 1 ? hi * 4 : 0;
@@ -170,7 +169,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     // bias gradient: column sums of the gy fragments, taken by the waves of the first pair-chunk's first input half (every output channel once per K share)
-    const bool do_bias = (a.db_partials != nullptr) & (pc == 0) & (cih == 0);
+    const bool do_bias = (R.db_partials != nullptr) & (pc == 0) & (cih == 0);
     float bsum = 0.f;
 
     for (int k = 0; k < nmine; ++k) {
@@ -253,10 +252,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const int64_t slot_eff = slot;
     if (do_bias) {
         const float v = bsum + __shfl_xor(bsum, 32, 64);             // the two lane halves hold disjoint pixels of one channel
-        if (lh == 0) a.db_partials[(slot_eff * a.ncg + cg) * C::CG + coh * 32 + (l & 31)] = v;
+        if (lh == 0) R.db_partials[(slot_eff * R.ncg + cg) * C::CG + coh * 32 + (l & 31)] = v;
     }
     if (!live) return;
-    float* dst = a.partials + ((slot_eff * a.nchunks + chunk) * a.ncg + cg) * (C::CG * 9 * 32);
+    float* dst = R.partials + ((slot_eff * R.nchunks + chunk) * R.ncg + cg) * (C::CG * 9 * 32);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
@@ -305,7 +304,20 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
     a.ntx = p.ntx; a.nty = p.nty; a.ntiles = p.ntiles; a.nslots = p.nslots; a.nchunks = p.nchunks; a.ncg = p.ncg;
     a.partials = d->partials;
     a.db_partials = d->db ? d->partials + p.dw_floats : nullptr;
-    const unsigned grid = (unsigned)(p.nslots * p.npc * p.ncg);
+    if (p.npc * p.ncg > TR_WG_MAX_ROLES) return -1;
+    WgRoles roles;
+    memset(&roles, 0, sizeof(roles));
+    roles.nroles = p.npc * p.ncg;
+    for (int cg = 0; cg < p.ncg; ++cg)
+        for (int pc = 0; pc < p.npc; ++pc) {
+            WgRole& r = roles.r[pc + p.npc * cg];
+            r.pc = pc; r.cg = cg;
+            r.in_c = d->in.c;
+            r.gy_coff = d->gy.coff; r.gy_c = d->gy.c;
+            r.nchunks = p.nchunks; r.ncg = p.ncg;
+            r.partials = a.partials; r.db_partials = a.db_partials;
+        }
+    const unsigned grid = (unsigned)(p.nslots * roles.nroles);
 #define TR_WGR_LAUNCH(CT, NT)                                                                                           \
     {                                                                                                                   \
         constexpr int lds = 2 * WCfg<NT>::STAGE;                                                                         \
@@ -315,7 +327,7 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
             hipFuncSetAttribute((const void*)wgrad_ring_kernel<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL((wgrad_ring_kernel<CT, NT>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, p.npc);          \
+        hipLaunchKernelGGL((wgrad_ring_kernel<CT, NT>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);          \
     }
     if (d->compute == TR_BF16) {
         if (p.cgw == 64) TR_WGR_LAUNCH(TR_BF16, 2) else TR_WGR_LAUNCH(TR_BF16, 1)
@@ -324,6 +336,75 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
     }
 #undef TR_WGR_LAUNCH
     return tr::launch_status("tr_wgrad3x3(ring)");
+}
+
+int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc, int* nslots_out) {
+    const char* impl = getenv("TRAINNER_WGRAD_IMPL");
+    if (impl && !strcmp(impl, "reg")) return -1;
+    if (getenv("TRAINNER_WGRAD_MULTI") && !strcmp(getenv("TRAINNER_WGRAD_MULTI"), "0")) return -1;
+    const tr_wgrad3x3_desc& d0 = descs[0];
+    if (d0.ksize != 3 || (d0.compute != TR_BF16 && d0.compute != TR_F16) || d0.in_mode != TR_IN_DIRECT) return -1;
+    if ((int64_t)d0.h * d0.w * d0.in.cstride * 2 >= (int64_t)0x7fff0000 || (int64_t)d0.h * d0.w * d0.gy.cstride * 2 >= (int64_t)0x7fff0000) return -1;
+    if ((int64_t)d0.n * d0.h * d0.w < 256 * 512 && !(impl && !strcmp(impl, "ring"))) return -1;
+    WgRoles roles;
+    memset(&roles, 0, sizeof(roles));
+    int nr = 0;
+    for (int k = 0; k < ndesc; ++k) {
+        const tr_wgrad3x3_desc& d = descs[k];
+        // one x buffer and one gy buffer, x slices starting at the same channel; same geometry and arithmetic
+        if (d.ksize != 3 || d.compute != d0.compute || d.in_mode != TR_IN_DIRECT || d.pad_mode != d0.pad_mode || d.n != d0.n || d.h != d0.h || d.w != d0.w) return -1;
+        if (d.in.ptr != d0.in.ptr || d.in.cstride != d0.in.cstride || d.in.coff != d0.in.coff || d.gy.ptr != d0.gy.ptr || d.gy.cstride != d0.gy.cstride) return -1;
+        if (d.cin % 8 != 0 || d.cout % 8 != 0) return -1;
+        const int nchunks = (d.cin + 31) / 32, npc = (nchunks + 1) / 2, ncg = (d.cout + 31) / 32;
+        if (nr + npc * ncg > TR_WG_MAX_ROLES) return -1;
+        for (int cg = 0; cg < ncg; ++cg)
+            for (int pc = 0; pc < npc; ++pc) {
+                WgRole& r = roles.r[nr++];
+                r.pc = pc; r.cg = cg;
+                r.in_c = d.in.c;
+                r.gy_coff = d.gy.coff; r.gy_c = d.gy.c;
+                r.nchunks = nchunks; r.ncg = ncg;
+            }
+    }
+    roles.nroles = nr;
+    WgRingPlan g = wgrad_ring_plan(d0.n, d0.h, d0.w, 64, 32);          // tile geometry only
+    int nslots = 256 / nr;
+    if (nslots > g.ntiles) nslots = g.ntiles;
+    if (nslots >= 8) nslots &= ~7;
+    if (nslots < 1) return -1;
+    // partial blocks: every conv keeps the single-launch layout with this slot count, in its own workspace
+    nr = 0;
+    for (int k = 0; k < ndesc; ++k) {
+        const tr_wgrad3x3_desc& d = descs[k];
+        const int nchunks = (d.cin + 31) / 32, npc = (nchunks + 1) / 2, ncg = (d.cout + 31) / 32;
+        const size_t dw_floats = (size_t)nslots * nchunks * ncg * 32 * 9 * 32, db_floats = (size_t)nslots * ncg * 32;
+        if (!d.partials || d.partials_bytes < (dw_floats + db_floats) * sizeof(float)) return -1;
+        for (int i = 0; i < npc * ncg; ++i) {
+            roles.r[nr].partials = d.partials;
+            roles.r[nr].db_partials = d.db ? d.partials + dw_floats : nullptr;
+            ++nr;
+        }
+    }
+    WgArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = d0.n; a.h = d0.h; a.w = d0.w;
+    a.up = 0; a.shift = 0;
+    a.ih = d0.h; a.iw = d0.w; a.hin = d0.h; a.win = d0.w;
+    a.replicate = d0.pad_mode == TR_PAD_REPLICATE;
+    a.in = d0.in; a.gy = d0.gy;
+    a.ntx = g.ntx; a.nty = g.nty; a.ntiles = g.ntiles; a.nslots = nslots;
+    const unsigned grid = (unsigned)(nslots * roles.nroles);
+    constexpr int lds = 2 * WCfg<1>::STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    if (d0.compute == TR_BF16) hipLaunchKernelGGL((wgrad_ring_kernel<TR_BF16, 1>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
+    else hipLaunchKernelGGL((wgrad_ring_kernel<TR_F16, 1>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
+    *nslots_out = nslots;
+    return tr::launch_status("tr_wgrad3x3_multi(ring)");
 }
 
 }  // namespace tr

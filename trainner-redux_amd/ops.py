@@ -177,6 +177,24 @@ def wgrad3x3(*, n, h, w, cin, cout, compute, inp: L.View, gy: L.View, dw: torch.
     L.check(L.lib().tr_wgrad3x3(stream_ptr(), C.byref(d)), "tr_wgrad3x3")
 
 
+def wgrad3x3_multi(convs, *, n, h, w, compute, pad_mode=L.PAD_ZEROS, accumulate=False):
+    """Weight / bias gradients of several 3x3 convs over channel slices of one input buffer and one output-gradient buffer (a dense block) in one
+    launch (tr_wgrad3x3_multi).  `convs`: dicts with cin, cout, inp, gy (views), dw, db (tensors or None), workspace (its own tensor per conv)."""
+    descs = (L.Wgrad3x3Desc * len(convs))()
+    for d, c in zip(descs, convs):
+        d.n, d.h, d.w, d.cin, d.cout = n, h, w, c["cin"], c["cout"]
+        d.compute, d.in_mode, d.pad_mode, d.accumulate = compute, L.IN_DIRECT, pad_mode, 1 if accumulate else 0
+        d.inp, d.gy = c["inp"], c["gy"]
+        d.ksize, d.dw_ld = 3, 0
+        dw, db, ws = c["dw"], c.get("db"), c["workspace"]
+        assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == c["cout"] * c["cin"] * 9
+        d.dw = dw.data_ptr()
+        d.db = db.data_ptr() if db is not None else None
+        d.partials = ws.data_ptr()
+        d.partials_bytes = ws.numel() * ws.element_size()
+    L.check(L.lib().tr_wgrad3x3_multi(stream_ptr(), descs, len(convs)), "tr_wgrad3x3_multi")
+
+
 def _f3(vals):
     return (C.c_float * 3)(*[float(v) for v in vals])
 
