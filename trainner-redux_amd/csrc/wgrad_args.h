@@ -13,18 +13,21 @@ struct WgArgs {
     int ntx, nty, ntiles, nslots, nchunks, ncg;
 };
 
-// Role table of the ring kernel: workgroup id = slot + nslots * role.  A role is one (conv, 64-input-channel block, output group) of the launch;
-// a single conv has npc x ncg roles, tr_wgrad3x3_multi the union over the convs of a dense block, which read channel slices of the SAME two
-// buffers: the roles of a slot walk the same tiles on one XCD, so every x / gy byte is fetched from memory once per launch, not once per conv.
+// Role table of the ring kernel: workgroup id = slot + nslots * role.  A role is one 64-input-channel block of x against one (32-wide kernel) or
+// two (64-wide kernel) 32-channel output groups, which need not belong to the same conv; a single conv has npc x ncg roles, tr_wgrad3x3_multi
+// pairs up the output groups of the convs of a dense block, which read channel slices of the SAME two buffers: the roles of a slot walk the
+// same tiles on one XCD, so every x / gy byte is fetched from memory once per launch, not once per conv, and an x tile staged in LDS serves two
+// output groups.
 constexpr int TR_WG_MAX_ROLES = 16;
 struct WgRole {
-    int pc, cg;            // 64-channel input block, output group of this role's conv
-    int in_c;              // input channels of the conv (x channels at and beyond it read as zero)
-    int gy_coff, gy_c;     // channel offset / count of the conv's output gradient inside the gy buffer (gy_coff is absolute: view offset included)
-    int nchunks, ncg;      // partial layout of the conv: [slot][nchunks][ncg][CG][9][32]
-    int pad_;
-    float* partials;
-    float* db_partials;    // [slot][ncg][CG] or null
+    int pc;                // 64-channel input block
+    int in_c;              // input channels staged (x channels at and beyond it read as zero): the larger of the two halves' convs
+    // per 32-channel output half (the 32-wide kernel uses half 0 only; a dead half has gy_c = 0 and nchunks = 0):
+    int gy_coff[2], gy_c[2];   // channel offset (absolute: view offset included) / count of the half's output gradient inside the gy buffer
+    int nchunks[2], ncg[2];    // partial layout of the half's conv in 32-wide groups: [slot][nchunks][ncg][32][9][32] (a 64-wide group = 2 of them)
+    int cg[2];                 // the half's 32-wide group index in that layout
+    float* partials[2];
+    float* db_partials[2];     // [slot][ncg][32] or null
 };
 struct WgRoles {
     int nroles;

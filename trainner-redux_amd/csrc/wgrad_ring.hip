@@ -80,7 +80,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     // workgroup id = slot + nslots * role (wgrad_args.h): with nslots a multiple of 8 the workgroups that walk the SAME tiles share an XCD's L2
     const int slot = blockIdx.x % a.nslots;
     const WgRole& R = roles.r[blockIdx.x / a.nslots];
-    const int pc = R.pc, cg = R.cg;
+    const int pc = R.pc;
     // tile walk: slot s takes tiles s + k * nslots (dealing the slots of one XCD a run of consecutive tiles instead, for halo reuse in its L2,
     // measured +5-10 % FETCH_SIZE and no change in time: the neighbours in a run are not in step)
     const int first = slot;
@@ -133,9 +133,10 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
                 const int col = gp & 31;
                 if (NT == 2) s ^= ((col >> 1) & 1) << 2;
                 const int oy = y0 + (gp >> 5), ox = x0 + col;
-                const int c0 = cg * C::CG + s * 8;
-                const bool ok = (oy < a.h) & (ox < a.w) & (c0 + 8 <= R.gy_c);
-                const unsigned off = (unsigned)(((int64_t)oy * a.w + ox) * gy_pix_bytes + (int64_t)(R.gy_coff + c0) * 2);
+                const int hf = NT == 2 ? s >> 2 : 0;              // 32-channel output half of the piece: its own slice of the gy buffer
+                const int c0 = (NT == 2 ? s & 3 : s) * 8;
+                const bool ok = (oy < a.h) & (ox < a.w) & (c0 + 8 <= R.gy_c[hf]);
+                const unsigned off = (unsigned)(((int64_t)oy * a.w + ox) * gy_pix_bytes + (int64_t)(R.gy_coff[hf] + c0) * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(gy_rsrc, (__attribute__((address_space(3))) void*)(st + X_BYTES + p0 * 16), 16, ok ? off : OOB, 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile k has landed (D = 1: it was issued while the consumers worked on tile k - 1)
@@ -152,7 +153,8 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const int cih = wv & 1;                       // input-channel half of the workgroup's 64
     const int hi = wv >> 1;                       // NT 1: pixel-row half of the tile ; NT 2: output-channel half
     const int chunk = pc * 2 + cih;               // 32-channel chunk of the partial layout
-    const bool live = chunk < R.nchunks;          // a 32-channel tail (cin = 96, 160): the other half of the last pair has nothing to do
+    const int hf = NT == 2 ? hi : 0;              // output half of this wave
+    const bool live = chunk < R.nchunks[hf];          // a 32-channel tail (cin = 96, 160): the other half of the last pair has nothing to do
     const int lh = l >> 5, li = l & 15, q = li >> 2, p = li & 3;
     const int i0 = ((l >> 4) & 1) * 16;
     const int rbase = NT == 1 ? hi * 4 : 0;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     // bias gradient: column sums of the gy fragments, taken by the waves of the first pair-chunk's first input half (every output channel once per K share)
-    const bool do_bias = (R.db_partials != nullptr) & (pc == 0) & (cih == 0);
+    const bool do_bias = (R.db_partials[hf] != nullptr) & (pc == 0) & (cih == 0);
     float bsum = 0.f;
 
     for (int k = 0; k < nmine; ++k) {
@@ -248,19 +250,19 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
         }
         bsum += xch[9 * 16 * 64 + l];
     }
-    // partial block of this wave: [slot][chunk][cg][co_local CG][tap 9][ci_local 32]
+    // partial block of this wave: [slot][chunk][32-wide group][co_local 32][tap 9][ci_local 32] of its half's conv
     const int64_t slot_eff = slot;
     if (do_bias) {
         const float v = bsum + __shfl_xor(bsum, 32, 64);             // the two lane halves hold disjoint pixels of one channel
-        if (lh == 0) R.db_partials[(slot_eff * R.ncg + cg) * C::CG + coh * 32 + (l & 31)] = v;
+        if (lh == 0) R.db_partials[hf][(slot_eff * R.ncg[hf] + R.cg[hf]) * 32 + (l & 31)] = v;
     }
     if (!live) return;
-    float* dst = R.partials + ((slot_eff * R.nchunks + chunk) * R.ncg + cg) * (C::CG * 9 * 32);
+    float* dst = R.partials[hf] + ((slot_eff * R.nchunks[hf] + chunk) * R.ncg[hf] + R.cg[hf]) * (32 * 9 * 32);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const int co = coh * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+            const int co = (reg & 3) + 8 * (reg >> 2) + 4 * lh;
             dst[(co * 9 + tap) * 32 + (l & 31)] = acc[tap][reg];
         }
 #endif
@@ -308,14 +310,19 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
     WgRoles roles;
     memset(&roles, 0, sizeof(roles));
     roles.nroles = p.npc * p.ncg;
+    const int halves = p.cgw / 32;
     for (int cg = 0; cg < p.ncg; ++cg)
         for (int pc = 0; pc < p.npc; ++pc) {
             WgRole& r = roles.r[pc + p.npc * cg];
-            r.pc = pc; r.cg = cg;
+            r.pc = pc;
             r.in_c = d->in.c;
-            r.gy_coff = d->gy.coff; r.gy_c = d->gy.c;
-            r.nchunks = p.nchunks; r.ncg = p.ncg;
-            r.partials = a.partials; r.db_partials = a.db_partials;
+            for (int hf = 0; hf < halves; ++hf) {
+                const int c0 = cg * p.cgw + hf * 32;
+                r.gy_coff[hf] = d->gy.coff + c0;
+                r.gy_c[hf] = d->gy.c - c0 < 0 ? 0 : (d->gy.c - c0 > 32 ? 32 : d->gy.c - c0);
+                r.nchunks[hf] = p.nchunks; r.ncg[hf] = p.ncg * halves; r.cg[hf] = cg * halves + hf;
+                r.partials[hf] = a.partials; r.db_partials[hf] = a.db_partials;
+            }
         }
     const unsigned grid = (unsigned)(p.nslots * roles.nroles);
 #define TR_WGR_LAUNCH(CT, NT)                                                                                           \
@@ -346,9 +353,10 @@ int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc
     if (d0.ksize != 3 || (d0.compute != TR_BF16 && d0.compute != TR_F16) || d0.in_mode != TR_IN_DIRECT) return -1;
     if ((int64_t)d0.h * d0.w * d0.in.cstride * 2 >= (int64_t)0x7fff0000 || (int64_t)d0.h * d0.w * d0.gy.cstride * 2 >= (int64_t)0x7fff0000) return -1;
     if ((int64_t)d0.n * d0.h * d0.w < 256 * 512 && !(impl && !strcmp(impl, "ring"))) return -1;
-    WgRoles roles;
-    memset(&roles, 0, sizeof(roles));
-    int nr = 0;
+    // 32-wide output units (conv, 64-channel input block, group), paired up per input block into 64-wide roles: an x tile staged in LDS serves two
+    struct Unit { int k, pc, cg; };
+    Unit units[3][2 * TR_WG_MAX_ROLES];
+    int nu[3] = {0, 0, 0};
     for (int k = 0; k < ndesc; ++k) {
         const tr_wgrad3x3_desc& d = descs[k];
         // one x buffer and one gy buffer, x slices starting at the same channel; same geometry and arithmetic
@@ -356,35 +364,49 @@ int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc
         if (d.in.ptr != d0.in.ptr || d.in.cstride != d0.in.cstride || d.in.coff != d0.in.coff || d.gy.ptr != d0.gy.ptr || d.gy.cstride != d0.gy.cstride) return -1;
         if (d.cin % 8 != 0 || d.cout % 8 != 0) return -1;
         const int nchunks = (d.cin + 31) / 32, npc = (nchunks + 1) / 2, ncg = (d.cout + 31) / 32;
-        if (nr + npc * ncg > TR_WG_MAX_ROLES) return -1;
-        for (int cg = 0; cg < ncg; ++cg)
-            for (int pc = 0; pc < npc; ++pc) {
-                WgRole& r = roles.r[nr++];
-                r.pc = pc; r.cg = cg;
-                r.in_c = d.in.c;
-                r.gy_coff = d.gy.coff; r.gy_c = d.gy.c;
-                r.nchunks = nchunks; r.ncg = ncg;
+        if (npc > 3) return -1;
+        for (int pc = 0; pc < npc; ++pc)
+            for (int cg = 0; cg < ncg; ++cg) {
+                if (nu[pc] >= 2 * TR_WG_MAX_ROLES) return -1;
+                units[pc][nu[pc]++] = Unit{k, pc, cg};
             }
     }
-    roles.nroles = nr;
+    const int nr = (nu[0] + 1) / 2 + (nu[1] + 1) / 2 + (nu[2] + 1) / 2;
+    if (nr > TR_WG_MAX_ROLES) return -1;
     WgRingPlan g = wgrad_ring_plan(d0.n, d0.h, d0.w, 64, 32);          // tile geometry only
     int nslots = 256 / nr;
     if (nslots > g.ntiles) nslots = g.ntiles;
     if (nslots >= 8) nslots &= ~7;
     if (nslots < 1) return -1;
     // partial blocks: every conv keeps the single-launch layout with this slot count, in its own workspace
-    nr = 0;
+    size_t dwf[64];
     for (int k = 0; k < ndesc; ++k) {
         const tr_wgrad3x3_desc& d = descs[k];
-        const int nchunks = (d.cin + 31) / 32, npc = (nchunks + 1) / 2, ncg = (d.cout + 31) / 32;
-        const size_t dw_floats = (size_t)nslots * nchunks * ncg * 32 * 9 * 32, db_floats = (size_t)nslots * ncg * 32;
-        if (!d.partials || d.partials_bytes < (dw_floats + db_floats) * sizeof(float)) return -1;
-        for (int i = 0; i < npc * ncg; ++i) {
-            roles.r[nr].partials = d.partials;
-            roles.r[nr].db_partials = d.db ? d.partials + dw_floats : nullptr;
-            ++nr;
-        }
+        const int nchunks = (d.cin + 31) / 32, ncg = (d.cout + 31) / 32;
+        dwf[k] = (size_t)nslots * nchunks * ncg * 32 * 9 * 32;
+        const size_t db_floats = (size_t)nslots * ncg * 32;
+        if (ndesc > 64 || !d.partials || d.partials_bytes < (dwf[k] + db_floats) * sizeof(float)) return -1;
     }
+    WgRoles roles;
+    memset(&roles, 0, sizeof(roles));
+    roles.nroles = nr;
+    int ri = 0;
+    for (int pc = 0; pc < 3; ++pc)
+        for (int u = 0; u < nu[pc]; u += 2) {
+            WgRole& r = roles.r[ri++];
+            r.pc = pc;
+            for (int hf = 0; hf < 2 && u + hf < nu[pc]; ++hf) {
+                const Unit& un = units[pc][u + hf];
+                const tr_wgrad3x3_desc& d = descs[un.k];
+                const int c0 = un.cg * 32;
+                if (d.in.c > r.in_c) r.in_c = d.in.c;
+                r.gy_coff[hf] = d.gy.coff + c0;
+                r.gy_c[hf] = d.gy.c - c0 > 32 ? 32 : d.gy.c - c0;
+                r.nchunks[hf] = (d.cin + 31) / 32; r.ncg[hf] = (d.cout + 31) / 32; r.cg[hf] = un.cg;
+                r.partials[hf] = d.partials;
+                r.db_partials[hf] = d.db ? d.partials + dwf[un.k] : nullptr;
+            }
+        }
     WgArgs a;
     memset(&a, 0, sizeof(a));
     a.n = d0.n; a.h = d0.h; a.w = d0.w;
@@ -394,15 +416,15 @@ int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc
     a.in = d0.in; a.gy = d0.gy;
     a.ntx = g.ntx; a.nty = g.nty; a.ntiles = g.ntiles; a.nslots = nslots;
     const unsigned grid = (unsigned)(nslots * roles.nroles);
-    constexpr int lds = 2 * WCfg<1>::STAGE;
+    constexpr int lds = 2 * WCfg<2>::STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_F16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (d0.compute == TR_BF16) hipLaunchKernelGGL((wgrad_ring_kernel<TR_BF16, 1>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
-    else hipLaunchKernelGGL((wgrad_ring_kernel<TR_F16, 1>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
+    if (d0.compute == TR_BF16) hipLaunchKernelGGL((wgrad_ring_kernel<TR_BF16, 2>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
+    else hipLaunchKernelGGL((wgrad_ring_kernel<TR_F16, 2>), dim3(grid), dim3((NCW + NLW) * 64), lds, st, a, roles);
     *nslots_out = nslots;
     return tr::launch_status("tr_wgrad3x3_multi(ring)");
 }
