@@ -36,7 +36,15 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-constexpr int TW = 32, TH = 8, HALO_W = TW + 2, HALO_H = TH + 2;
+// tile height: 8 rows / two stages (one tile in flight behind the one in work) or 4 rows / three stages (two in flight).  Measured on the dense-block
+// shapes: 4 rows gain on the narrow single launches (128 -> 32: 0.119 -> 0.106 ms) and lose on the fused launch (0.492 -> 0.512 ms per block: the
+// halo rows are 1.5x instead of 1.25x of a tile and there are twice as many barriers), which is where the time is
+#ifndef TR_WGR_TH
+#define TR_WGR_TH 8
+#endif
+constexpr int TW = 32, TH = TR_WGR_TH, HALO_W = TW + 2, HALO_H = TH + 2;
+constexpr int NSTAGE = TH == 4 ? 3 : 2;                    // LDS stages: 4-row tiles leave room for a third, i.e. two tiles in flight behind the one in work
+static_assert(NSTAGE == 2 || NSTAGE == 3, "vmcnt bookkeeping of the loader loop");
 constexpr int NCW = 4, NLW = 4;
 constexpr int XPIX = 128;                                   // 64 input channels x 2 bytes per halo pixel
 constexpr int X_ITEMS = HALO_H * HALO_W * 8;                // 16-byte slots
@@ -63,7 +71,7 @@ struct WCfg {
     static constexpr int G_IT = G_ITEMS / (64 * NLW);
     static constexpr int STAGE = X_BYTES + G_BYTES;
     static constexpr int NP = X_IT + G_IT;
-    static constexpr int NSTEP = NT == 1 ? 8 : 16;           // 16-pixel K steps per wave and tile
+    static constexpr int NSTEP = NT == 1 ? TH : 2 * TH;      // 16-pixel K steps per wave and tile
     static_assert(G_ITEMS % (64 * NLW) == 0, "gy pieces");
 };
 
@@ -91,15 +99,14 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
         const int lw = wv - NCW;
         const int64_t in_pix_bytes = (int64_t)a.in.cstride * 2, gy_pix_bytes = (int64_t)a.gy.cstride * 2;
         const unsigned in_img = (unsigned)((int64_t)a.hin * a.win * in_pix_bytes), gy_img = (unsigned)((int64_t)a.h * a.w * gy_pix_bytes);
-        for (int k = 0; k < nmine; ++k) {
-            if (TR_WGR_ABL & 2) { __builtin_amdgcn_s_barrier(); continue; }
+        auto issue = [&](int k, int stage) {
             int t_ = first + k * a.nslots;
             const int x0 = (t_ % a.ntx) * TW; t_ /= a.ntx;
             const int y0 = (t_ % a.nty) * TH;
             const int nb = t_ / a.nty;
             const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * a.hin * a.win * in_pix_bytes), 0, in_img, 0x00020000);
             const auto gy_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.gy.ptr + (int64_t)nb * a.h * a.w * gy_pix_bytes), 0, gy_img, 0x00020000);
-            char* st = smem + (k & 1) * C::STAGE;
+            char* st = smem + stage * C::STAGE;
             // x halo: position P = pixel * 8 + stored slot; the 64-byte halves of a pixel are swapped where bit 1 of its COLUMN is set (bank swizzle
             // of the transposed reads, on the source address: the LDS image is position-linear)
 #pragma unroll
@@ -139,8 +146,25 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
                 const unsigned off = (unsigned)(((int64_t)oy * a.w + ox) * gy_pix_bytes + (int64_t)(R.gy_coff[hf] + c0) * 2);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(gy_rsrc, (__attribute__((address_space(3))) void*)(st + X_BYTES + p0 * 16), 16, ok ? off : OOB, 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile k has landed (D = 1: it was issued while the consumers worked on tile k - 1)
+        };
+        // NSTAGE - 1 tiles in flight while the consumers work on tile k: tile k + NSTAGE - 1 is requested right AFTER barrier k, into the stage of
+        // tile k - 1 (its consumption ended before that barrier).  Loads retire in order: tile k has landed when only the NP pieces of each
+        // later request are outstanding.
+        constexpr int D = NSTAGE - 1;
+        int stage_n = 0;                                         // stage of the next tile to request
+        for (int k = 0; k < D && k < nmine; ++k) {
+            if (!(TR_WGR_ABL & 2)) issue(k, stage_n);
+            stage_n = stage_n == NSTAGE - 1 ? 0 : stage_n + 1;
+        }
+        for (int k = 0; k < nmine; ++k) {
+            const int later = min(nmine - 1 - k, D - 1);         // tiles requested behind tile k at this point
+            if (later >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if (k + D < nmine) {
+                if (!(TR_WGR_ABL & 2)) issue(k + D, stage_n);
+                stage_n = stage_n == NSTAGE - 1 ? 0 : stage_n + 1;
+            }
         }
         if (NT == 1) {                                           // the consumers' exchange of the two pixel-row halves (below)
             __builtin_amdgcn_s_barrier();
@@ -157,7 +181,7 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const bool live = chunk < R.nchunks[hf];          // a 32-channel tail (cin = 96, 160): the other half of the last pair has nothing to do
     const int lh = l >> 5, li = l & 15, q = li >> 2, p = li & 3;
     const int i0 = ((l >> 4) & 1) * 16;
-    const int rbase = NT == 1 ? hi * 4 : 0;
+    const int rbase = NT == 1 ? hi * (TH / 2) : 0;
     const int coh = NT == 2 ? hi : 0;
     // lane terms of the fragment addresses (everything else is an immediate): x by kx, gy once
     int xo[3];
@@ -174,11 +198,13 @@ __global__ __launch_bounds__((NCW + NLW) * 64) void wgrad_ring_kernel(WgArgs a, 
     const bool do_bias = (R.db_partials[hf] != nullptr) & (pc == 0) & (cih == 0);
     float bsum = 0.f;
 
+    int stage_c = 0;
     for (int k = 0; k < nmine; ++k) {
         __builtin_amdgcn_s_barrier();
+        const char* st = smem + stage_c * C::STAGE;
+        stage_c = stage_c == NSTAGE - 1 ? 0 : stage_c + 1;
         if (!live || (TR_WGR_ABL & 1)) continue;
         // the wave's first tile row goes into the base pointers: every fragment address below is base + immediate
-        const char* st = smem + (k & 1) * C::STAGE;
         const char* xb[3] = {st + xo[0] + rbase * (HALO_W * XPIX), st + xo[1] + rbase * (HALO_W * XPIX), st + xo[2] + rbase * (HALO_W * XPIX)};
         const char* gb = st + X_BYTES + go + rbase * (32 * C::GPIX);
         constexpr int NI = C::NSTEP * 9;          // (K step, tap) items, one MFMA each
@@ -327,8 +353,8 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
     const unsigned grid = (unsigned)(p.nslots * roles.nroles);
 #define TR_WGR_LAUNCH(CT, NT)                                                                                           \
     {                                                                                                                   \
-        constexpr int lds = 2 * WCfg<NT>::STAGE;                                                                         \
-        static_assert(lds <= LDS_MAX, "two stages");                                                                    \
+        constexpr int lds = NSTAGE * WCfg<NT>::STAGE;                                                                    \
+        static_assert(lds <= LDS_MAX, "stages");                                                                        \
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             hipFuncSetAttribute((const void*)wgrad_ring_kernel<CT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
@@ -416,7 +442,7 @@ int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc
     a.in = d0.in; a.gy = d0.gy;
     a.ntx = g.ntx; a.nty = g.nty; a.ntiles = g.ntiles; a.nslots = nslots;
     const unsigned grid = (unsigned)(nslots * roles.nroles);
-    constexpr int lds = 2 * WCfg<2>::STAGE;
+    constexpr int lds = NSTAGE * WCfg<2>::STAGE;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)wgrad_ring_kernel<TR_BF16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
