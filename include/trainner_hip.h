@@ -117,7 +117,9 @@ int    tr_pack_winograd(void* stream, const float* w_oihw, float* dst, int cout,
 int    tr_conv3x3_winograd_f32(void* stream, const tr_conv3x3_desc* d);
 /* The same contract as a fused Winograd F(4x4, 3x3) kernel (h and w multiples of 4): 0.5625 of the MFMA cycles of the F(2x2, 3x3) form, every
  * operation still an fp32 add / multiply / MFMA; differs from tr_conv3x3 by fp32 rounding (~2e-6 relative per layer; F(2x2): ~4e-7).
- * `wpacked` comes from tr_pack_winograd43 (U = G g G^T, 6 x 6 per (cout, cin) pair, in the kernel's fragment order). */
+ * `wpacked` comes from tr_pack_winograd43 (U = G g G^T, 6 x 6 per (cout, cin) pair, in the kernel's fragment order).
+ * `out2` of THIS entry point, if set, receives max_pool2d(relu(out), 2, 2) at half resolution (fp32 view of cout channels, out2_scale 1,
+ * no mask): VGG19's conv -> ReLU -> MaxPool pairs (perceptual_fp16_loss.py:12-50) without reading the activation back. */
 size_t tr_winograd43_packed_bytes(int cin, int cout);
 int    tr_pack_winograd43(void* stream, const float* w_oihw, float* dst, int cout, int cin, int transpose);
 int    tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d);

@@ -582,6 +582,14 @@ def test_winograd43_f32_forward_and_input_gradient(cuda, shape):
                 act=L.ACT_RELU)
     assert rel_l2(out[..., 4:].permute(0, 3, 1, 2).cpu(), ref) < 5e-6
     assert torch.all(out[..., :4] == 3.0)
+    # pooled second output (conv -> ReLU -> MaxPool pairs of VGG19): pre-ReLU activation stored, max_pool2d(relu(.)) next to it, in a channel slice
+    pre = torch.full((n, h, w, cout), 3.0, device=cuda)
+    pooled = torch.full((n, h // 2, w // 2, cout + 4), 5.0, device=cuda)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(xd), out=ops.view(pre), wpacked=U, bias=b.float().to(cuda),
+                out2=ops.view(pooled, 4, cout))
+    assert rel_l2(pre.permute(0, 3, 1, 2).cpu(), F.conv2d(x, wt, b, padding=1)) < 5e-6
+    assert rel_l2(pooled[..., 4:].permute(0, 3, 1, 2).cpu(), F.max_pool2d(ref, 2, 2)) < 5e-6
+    assert torch.all(pooled[..., :4] == 5.0)
     if cin % 64 == 0:
         gy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
         m = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)

@@ -24,10 +24,13 @@ def check():
         xd = x.float().permute(0, 2, 3, 1).contiguous().to(dev)
         out = torch.full((n, h, w, cout + 4), 3.0, device=dev)
         U = ops.pack_winograd43(wt.float().to(dev))
-        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(xd), out=ops.view(out, 4, cout), wpacked=U, bias=b.float().to(dev), act=L.ACT_RELU)
+        pooled = torch.full((n, h // 2, w // 2, cout + 4), 5.0, device=dev)
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(xd), out=ops.view(out, 4, cout), wpacked=U, bias=b.float().to(dev), act=L.ACT_RELU,
+                    out2=ops.view(pooled, 0, cout))
         got = out[..., 4:].permute(0, 3, 1, 2).cpu()
         e = rel(got, ref)
-        ok = e < 1e-5 and bool((out[..., :4] == 3.0).all())
+        ep = rel(pooled[..., :cout].permute(0, 3, 1, 2).cpu(), F.max_pool2d(ref, 2, 2))
+        ok = e < 1e-5 and ep < 1e-5 and bool((out[..., :4] == 3.0).all()) and bool((pooled[..., cout:] == 5.0).all())
         # input-gradient form: transposed pack, mask
         gy = torch.randn(n, cout, h, w, dtype=torch.float64)
         m = torch.randn(n, cin, h, w, dtype=torch.float64)

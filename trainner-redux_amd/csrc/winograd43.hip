@@ -53,7 +53,7 @@ struct Wino43Args {
     int n, h, w, cin, cout;
     int act;
     float mask_slope;
-    tr_view in, out, mask;
+    tr_view in, out, mask, pool;
     const float* u;
     const float* bias;
     int nty, ntx, nchunks, nkg;
@@ -91,7 +91,9 @@ template <int V> struct QInt { static constexpr int value = V; };
 
 // MASK: the input-gradient form (ReLU-derivative mask on the output).  A template parameter because the two forms spend the epilogue's registers
 // differently: the masked form holds the round's four mask vectors across the exchange barrier, the plain form holds both bias vectors.
-template <bool MASK>
+// POOL: the epilogue also writes the 2x2 max pool of ReLU(out) at half resolution (VGG19's conv -> ReLU -> MaxPool pairs: the pool kernel would read
+// the whole activation back).
+template <bool MASK, bool POOL>
 __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* vst = (float*)smem;                       // two V stages; the exchange rounds of the epilogue alias them
@@ -351,6 +353,9 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
             const __amdgpu_buffer_rsrc_t mask_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((char*)a.mask.ptr + (int64_t)nb * mask_img + (a.mask.coff + kg * Q_KB) * 4), 0, (unsigned)mask_img, 0x00020000);
             const int ox0 = bx * 32 + (et & 7) * 4, oy0 = by * 16 + (et >> 3) * 4 + erl;
+            const int pool_img = (a.h >> 1) * (a.w >> 1) * a.pool.cstride * 4;
+            const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((char*)a.pool.ptr + (int64_t)nb * pool_img + (a.pool.coff + kg * Q_KB) * 4), 0, POOL ? (unsigned)pool_img : 0u, 0x00020000);
 #pragma unroll
             for (int round = 0; round < 4; ++round) {
                 const int rkh = round >> 1, rp = round & 1;
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                     for (int j = 0; j < 6; ++j) T[j] = *(const f32x4*)(tp + j * 2 * Q_TB * Q_TS);
                     const f32x4 s12 = T[1] + T[2], d12 = T[1] - T[2], s34 = T[3] + T[4], d34 = T[3] - T[4];
                     const f32x4 y[4] = {T[0] + s12 + s34, d12 + 2.f * d34, s12 + 4.f * s34, d12 + 8.f * d34 + T[5]};
+                    f32x4 pm[2];                                      // POOL: max of ReLU over the thread's two pixel pairs
 #pragma unroll
                     for (int sx = 0; sx < 4; ++sx) {
                         const int ox = ox0 + sx;
@@ -402,6 +408,29 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
                                                                out_rsrc, ok ? (pixi * a.out.cstride + kc) * 4 : (int)Q_OOB, 0, 0);
+                        if (POOL) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float r = fmaxf(v[e], 0.f);
+                                pm[sx >> 1][e] = (sx & 1) ? fmaxf(pm[sx >> 1][e], r) : r;
+                            }
+                        }
+                    }
+                    if (POOL) {
+                        // the other row of the 2 x 2 windows is held by the thread whose row bit (tid bit 3) differs: same wave, lane ^ 8
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pm[j][e] = fmaxf(pm[j][e], __shfl_xor(pm[j][e], 8, 64));
+                        if (erl == 0) {
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                const bool okp = oy < a.h && ox0 + 2 * j < a.w;
+                                const int pp = (oy >> 1) * (a.w >> 1) + ((ox0 >> 1) + j);
+                                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(pm[j][0]), __float_as_uint(pm[j][1]), __float_as_uint(pm[j][2]), __float_as_uint(pm[j][3])},
+                                                                       pool_rsrc, okp ? (pp * a.pool.cstride + kc) * 4 : (int)Q_OOB, 0, 0);
+                            }
+                        }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -467,20 +496,23 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     TR_REQUIRE(d->ksize == 3 && d->in_mode == TR_IN_DIRECT && d->pad_mode == TR_PAD_ZEROS, TR_EUNSUPPORTED,
                "tr_conv3x3_winograd43_f32: 3x3, direct input, zero padding only");
     TR_REQUIRE(d->act == TR_ACT_NONE || d->act == TR_ACT_RELU, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: activation %d is not built (none, ReLU)", d->act);
-    TR_REQUIRE(!d->res1.ptr && !d->res2.ptr && !d->out2.ptr && !d->sample_scale && d->mask_mode == 0, TR_EUNSUPPORTED,
-               "tr_conv3x3_winograd43_f32: residual / second output / per-sample scale / activation-derivative masks are not built");
+    TR_REQUIRE(!d->res1.ptr && !d->res2.ptr && !d->sample_scale && d->mask_mode == 0, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: residual / per-sample scale / activation-derivative masks are not built");
+    // out2 of this entry point: the 2x2 max pool of ReLU(out) at half resolution (fp32, cout channels), plain form only
+    TR_REQUIRE(!d->out2.ptr || (!d->mask.ptr && d->out2_scale == 1.f && q_view_ok(d->out2, d->cout)), TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: out2 (pooled output) needs an fp32 view of cout channels, scale 1, and no mask");
     TR_REQUIRE(q_view_ok(d->in, d->cin) && q_view_ok(d->out, d->cout) && (!d->mask.ptr || q_view_ok(d->mask, d->cout)) && d->wpacked, TR_EINVAL,
                "tr_conv3x3_winograd43_f32: fp32 views holding cin / cout channels and packed weights are required");
     TR_REQUIRE(((uintptr_t)d->wpacked) % 16 == 0, TR_EALIGN, "tr_conv3x3_winograd43_f32: wpacked must be 16-byte aligned");
     auto al = [](const tr_view& v) { return !v.ptr || (v.cstride % 4 == 0 && v.coff % 4 == 0 && ((uintptr_t)v.ptr) % 16 == 0); };
-    TR_REQUIRE(al(d->in) && al(d->out) && al(d->mask), TR_EALIGN, "tr_conv3x3_winograd43_f32: views must allow aligned 4-channel access");
+    TR_REQUIRE(al(d->in) && al(d->out) && al(d->mask) && al(d->out2), TR_EALIGN, "tr_conv3x3_winograd43_f32: views must allow aligned 4-channel access");
     TR_REQUIRE((int64_t)d->h * d->w * d->in.cstride * 4 < (int64_t)Q_OOB && (int64_t)d->h * d->w * d->out.cstride * 4 < (int64_t)Q_OOB &&
                    (!d->mask.ptr || (int64_t)d->h * d->w * d->mask.cstride * 4 < (int64_t)Q_OOB),
                TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: one image of the input / output / mask must stay below 2 GB (32-bit buffer offsets)");
     Wino43Args a;
     a.n = d->n; a.h = d->h; a.w = d->w; a.cin = d->cin; a.cout = d->cout;
     a.act = d->act; a.mask_slope = d->mask_slope;
-    a.in = d->in; a.out = d->out; a.mask = d->mask;
+    a.in = d->in; a.out = d->out; a.mask = d->mask; a.pool = d->out2;
     a.u = (const float*)d->wpacked; a.bias = d->bias;
     a.nty = (d->h + 15) / 16; a.ntx = (d->w + 31) / 32;
     a.nchunks = d->cin / Q_CK; a.nkg = d->cout / Q_KB;
@@ -488,9 +520,10 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: grid too large");
     static const hipError_t attr = [] {
-        const hipError_t e0 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
-        const hipError_t e1 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
-        return e0 != hipSuccess ? e0 : e1;
+        const hipError_t e0 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+        const hipError_t e1 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+        const hipError_t e2 = hipFuncSetAttribute((const void*)winograd43_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Q_SMEM);
+        return e0 != hipSuccess ? e0 : e1 != hipSuccess ? e1 : e2;
     }();
     TR_REQUIRE(attr == hipSuccess, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: the device does not grant %d bytes of LDS per workgroup", Q_SMEM);
     static const int ncu = [] {
@@ -499,7 +532,8 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
         return v;
     }();
     const unsigned grid = (unsigned)(nblk < ncu ? nblk : ncu);          // persistent: one workgroup per CU walks its tiles
-    if (a.mask.ptr) hipLaunchKernelGGL(winograd43_f32_kernel<true>, dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(winograd43_f32_kernel<false>, dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    if (a.mask.ptr) hipLaunchKernelGGL((winograd43_f32_kernel<true, false>), dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    else if (a.pool.ptr) hipLaunchKernelGGL((winograd43_f32_kernel<false, true>), dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((winograd43_f32_kernel<false, false>), dim3(grid), dim3(Q_THREADS), Q_SMEM, (hipStream_t)stream, a);
     return tr::launch_status("tr_conv3x3_winograd43_f32");
 }

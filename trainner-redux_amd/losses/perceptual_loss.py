@@ -205,7 +205,8 @@ class VGG(nn.Module):
             return ws
         self._ws.clear()
         e = lambda *s: torch.empty(*s, dtype=cdt, device=dev)  # noqa: E731
-        ws = dict(a0=e(n, h, w, 8), acts=[], feats_gt={}, scratch=[e(n, h, w, 64), e(n, h, w, 64)])
+        ws = dict(a0=e(n, h, w, 8), acts=[], feats_gt={}, scratch=[e(n, h, w, 64), e(n, h, w, 64)],
+                  scratch_pool=e(n, h // 2, w // 2, 64))      # pooled output of a conv + pool pair on the pass that keeps nothing
         hh, ww = h, w
         levels = {}
         for op in self.program:
@@ -238,6 +239,8 @@ class VGG(nn.Module):
         hh, ww = h, w
         first = True
         flip = 0
+        fuse_pool = not os.environ.get("TRAINNER_NO_POOL_FUSION")
+        pooled = None           # output of the pool op that the previous conv has already written (Winograd F(4,3) epilogue)
         for k, op in enumerate(self.program):
             if op[0] == "conv":
                 _, name, m, fused_relu, tapped = op
@@ -254,19 +257,32 @@ class VGG(nn.Module):
                     ops.conv3x3_stem(img.contiguous(), m.weight.data, m.bias.data, V(out), mean=IMAGENET_MEAN, std=IMAGENET_STD, pad_mode=L.PAD_REPLICATE,
                                      act=L.ACT_RELU if fused_relu else L.ACT_NONE)
                 else:
+                    nxt = self.program[k + 1] if k + 1 < len(self.program) else None
+                    kw = {}
+                    # conv -> (ReLU) -> MaxPool: the F(4,3) kernel writes max_pool2d(relu(out)) next to out, the pool kernel is skipped
+                    if fuse_pool and w43 and nxt is not None and nxt[0] == "pool" and (nxt[1] or fused_relu) and cur is not ws.get("_pool_view"):
+                        if keep:
+                            pooled = ws["acts"][k + 1]
+                        else:       # its own buffer: both ping-pong buffers are taken (this conv's input and output)
+                            pooled = ws["scratch_pool"].view(-1)[: n * (hh // 2) * (ww // 2) * m.cout].view(n, hh // 2, ww // 2, m.cout)
+                            ws["_pool_view"] = pooled
+                        kw["out2"] = V(pooled)
                     ops.conv3x3(n=n, h=hh, w=ww, cin=cur_c, cout=m.cout, compute=L.F32_WINOGRAD43 if w43 else L.F32_WINOGRAD if wino else cd,
                                 inp=V(cur, 0, cur_c), out=V(out), wpacked=pk[name][4 if w43 else 2 if wino else 0], bias=m.bias.data,
-                                act=L.ACT_RELU if fused_relu else L.ACT_NONE, pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS)
+                                act=L.ACT_RELU if fused_relu else L.ACT_NONE, pad_mode=L.PAD_REPLICATE if first else L.PAD_ZEROS, **kw)
                 first = False
                 cur, cur_c = out, m.cout
             else:
                 relu_first = op[1]
-                if keep:
-                    out = ws["acts"][k]
+                if pooled is not None:
+                    out, pooled = pooled, None
                 else:
-                    out = ws["scratch"][flip].view(-1)[: n * (hh // 2) * (ww // 2) * cur_c].view(n, hh // 2, ww // 2, cur_c)
-                    flip ^= 1
-                ops.maxpool2x2(V(cur), V(out), n, hh, ww, relu_first)
+                    if keep:
+                        out = ws["acts"][k]
+                    else:
+                        out = ws["scratch"][flip].view(-1)[: n * (hh // 2) * (ww // 2) * cur_c].view(n, hh // 2, ww // 2, cur_c)
+                        flip ^= 1
+                    ops.maxpool2x2(V(cur), V(out), n, hh, ww, relu_first)
                 hh, ww = hh // 2, ww // 2
                 cur = out
 
