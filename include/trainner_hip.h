@@ -256,6 +256,10 @@ typedef struct tr_pixel_loss_desc {
     float*  partials;         /* >= 1024 floats of scratch                   */
 } tr_pixel_loss_desc;
 int tr_pixel_loss(void* stream, const tr_pixel_loss_desc* d);
+/* The same criterion on the fp32 NHWC activation (n x h x w x c) that feeds F.max_pool2d(F.relu(.), 2, 2) (a tapped VGG19 conv in front of a
+ * pool, perceptual_fp16_loss.py:12-50,262-329), fused with that pool's backward: grad = grad_weight/numel * dcrit(pred - target)
+ * + max_pool2d_backward(gout) through the ReLU, written once (d->accumulate_grad is ignored; fp32 only).  gout: n x h/2 x w/2 x c. */
+int tr_pixel_loss_pool_bwd(void* stream, const tr_pixel_loss_desc* d, const float* gout, int n, int h, int w, int c);
 
 /* ---- U-Net discriminator pieces (archs/discriminator_arch.py:98-160) ---------------------------------------------------
  * 4x4 stride-2 pad-1 convs run as space-to-depth(2) + the 3x3 MFMA conv on expanded weights:

@@ -263,6 +263,36 @@ def test_wgrad3x3_is_bitwise_reproducible(cuda):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("kind_name", ["l1", "charbonnier", "mse"])
+def test_pixel_loss_fused_with_pool_backward(cuda, kind_name):
+    """tr_pixel_loss_pool_bwd: the criterion on a tapped fp32 activation that also feeds max_pool2d(relu(.), 2, 2)
+    (perceptual_fp16_loss.py:12-50: VGG19's conv -> ReLU -> MaxPool with the pre-ReLU feature tapped), gradient = loss term + the pool's
+    backward through the ReLU in one pass, against autograd (ties and non-positive windows included)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    kind = {"l1": L.LOSS_L1, "mse": L.LOSS_MSE, "charbonnier": L.LOSS_CHARBONNIER}[kind_name]
+    n, h, w, c = 2, 12, 20, 16
+    g = torch.Generator().manual_seed(31)
+    act = torch.randn(n, c, h, w, generator=g)
+    act[0, 0, 0, :4] = 0.7          # ties inside a window: the first maximal element takes the gradient
+    act[0, 1, :2, :2] = -1.0        # a window with no positive value: nothing flows through the ReLU
+    gt = torch.randn(n, c, h, w, generator=g)
+    gout = torch.randn(n, c, h // 2, w // 2, generator=g)
+    a = act.clone().requires_grad_(True)
+    eps = 1e-6
+    d = a - gt
+    crit = d.abs().mean() if kind == L.LOSS_L1 else (d * d).mean() if kind == L.LOSS_MSE else torch.sqrt(d * d + eps).mean()
+    lw = 0.37
+    (lw * crit + (F.max_pool2d(F.relu(a), 2, 2) * gout).sum()).backward()
+    ad, gtd, god = nhwc(act).to(cuda), nhwc(gt).to(cuda), nhwc(gout).to(cuda)
+    grad = torch.full((n, h, w, c), 9.0, device=cuda)
+    val = torch.zeros(1, device=cuda)
+    tot = torch.zeros(1, device=cuda)
+    ops.pixel_loss(kind, ad, gtd, val, value_weight=lw, total_out=tot, total_weight=lw, grad=grad, grad_weight=lw, eps=eps, pool_gout=god)
+    assert abs(val.item() - lw * crit.item()) < 1e-6 * max(1.0, abs(crit.item())) and abs(tot.item() - val.item()) < 1e-7
+    assert rel_l2(nchw(grad.cpu()), a.grad) < 1e-6
+
+
 def test_layout_and_pool(cuda):
     from trainner_redux_amd import _lib as L, ops
 

@@ -172,6 +172,7 @@ SYMBOLS = {
     "tr_maxpool2x2": (C.c_int, [C.c_void_p, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_pixel_loss": (C.c_int, [C.c_void_p, C.POINTER(PixelLossDesc)]),
+    "tr_pixel_loss_pool_bwd": (C.c_int, [C.c_void_p, C.POINTER(PixelLossDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_sumsq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tr_adamw_ema": (C.c_int, [C.c_void_p, C.POINTER(AdamWDesc)]),
 }

@@ -96,6 +96,61 @@ __global__ __launch_bounds__(256) void pixel_loss_kernel(const void* __restrict_
     if (threadIdx.x == 0) partials[blockIdx.x] = bs;
 }
 
+// tr_pixel_loss on the fp32 NHWC activation that feeds a ReLU + 2x2 max pool, fused with the pool's backward: one thread per (window, channel
+// quad) reads its four pixels of pred and target and the pooled gradient, writes grad = gscale * dcrit + route(gout) once.  The separate
+// sequence (tr_maxpool2x2_bwd, then an accumulating tr_pixel_loss) moved 6.25 values per element, this one 3.25.
+template <int KIND>
+__global__ __launch_bounds__(256) void pixel_loss_pool_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ gout,
+                                                                   float* __restrict__ grad, int n, int h, int w, int c, float gscale, float eps,
+                                                                   float* __restrict__ partials) {
+    __shared__ float sh[4];
+    float sum = 0.f;
+    const int ho = h >> 1, wo = w >> 1, c4 = c >> 2;
+    const int64_t total = (int64_t)n * ho * wo * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t t = i;
+        const int cq = (int)(t % c4) * 4; t /= c4;
+        const int x = (int)(t % wo); t /= wo;
+        const int y = (int)(t % ho);
+        const int nb = (int)(t / ho);
+        const int64_t p00 = (((int64_t)nb * h + 2 * y) * w + 2 * x) * c + cq;
+        const int64_t offs[4] = {p00, p00 + c, p00 + (int64_t)w * c, p00 + (int64_t)w * c + c};
+        float4 a[4], tg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a[k] = *(const float4*)(pred + offs[k]);
+            tg[k] = *(const float4*)(target + offs[k]);
+        }
+        const float4 g = *(const float4*)(gout + (((int64_t)nb * ho + y) * wo + x) * c + cq);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+        float o[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float av[4] = {((const float*)&a[0])[e], ((const float*)&a[1])[e], ((const float*)&a[2])[e], ((const float*)&a[3])[e]};
+            // first maximal element of relu(.) in window scan order takes the pooled gradient (ATen keeps the earliest index on ties); none at max <= 0
+            int km = 0;
+            float m = fmaxf(av[0], 0.f);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float r = fmaxf(av[k], 0.f);
+                if (r > m) { m = r; km = k; }
+            }
+            const float gp = m > 0.f ? gv[e] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v, dv;
+                elem<KIND>(av[k] - ((const float*)&tg[k])[e], eps, v, dv);
+                sum += v;
+                o[k][e] = dv * gscale + (k == km ? gp : 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(float4*)(grad + offs[k]) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+    }
+    const float bs = block_sum(sum, sh);
+    if (threadIdx.x == 0) partials[blockIdx.x] = bs;
+}
+
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ partials, int nparts, float scale, float* out,
                                                      float scale2, float* out2, int take_sqrt) {
     __shared__ float sh[4];
@@ -154,6 +209,33 @@ extern "C" int tr_pixel_loss(void* stream, const tr_pixel_loss_desc* d) {
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, d->partials, nb, d->value_weight * inv, d->value_out,
                        d->total_weight * inv, d->total_out, 0);
     return tr::launch_status("tr_pixel_loss(finish)");
+}
+
+extern "C" int tr_pixel_loss_pool_bwd(void* stream, const tr_pixel_loss_desc* d, const float* gout, int n, int h, int w, int c) {
+    TR_REQUIRE(d && d->pred && d->target && d->value_out && d->partials && d->grad && gout, TR_EINVAL, "tr_pixel_loss_pool_bwd: bad arguments");
+    TR_REQUIRE(d->kind >= TR_LOSS_L1 && d->kind <= TR_LOSS_CHARBONNIER, TR_EINVAL, "tr_pixel_loss_pool_bwd: unknown kind %d", d->kind);
+    TR_REQUIRE(d->dtype == TR_F32 && d->grad_dtype == TR_F32, TR_EUNSUPPORTED, "tr_pixel_loss_pool_bwd: fp32 activations and gradients only");
+    TR_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && h % 2 == 0 && w % 2 == 0 && c % 4 == 0 && d->numel == (int64_t)n * h * w * c, TR_EINVAL,
+               "tr_pixel_loss_pool_bwd: needs even h, w, channels in fours and numel = n*h*w*c");
+    TR_REQUIRE(((uintptr_t)d->pred) % 16 == 0 && ((uintptr_t)d->target) % 16 == 0 && ((uintptr_t)d->grad) % 16 == 0 && ((uintptr_t)gout) % 16 == 0, TR_EALIGN,
+               "tr_pixel_loss_pool_bwd: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = blocks_for(d->numel / 4);
+    const float inv = 1.f / (float)d->numel;
+    const float gscale = d->grad_weight * inv;
+#define TR_LAUNCH_LOSSP(K)                                                                                                         \
+    hipLaunchKernelGGL(pixel_loss_pool_bwd_kernel<K>, dim3(nb), dim3(256), 0, st, (const float*)d->pred, (const float*)d->target, gout, \
+                       (float*)d->grad, n, h, w, c, gscale, d->eps, d->partials)
+    switch (d->kind) {
+        case TR_LOSS_L1: TR_LAUNCH_LOSSP(TR_LOSS_L1); break;
+        case TR_LOSS_MSE: TR_LAUNCH_LOSSP(TR_LOSS_MSE); break;
+        default: TR_LAUNCH_LOSSP(TR_LOSS_CHARBONNIER);
+    }
+#undef TR_LAUNCH_LOSSP
+    int rc = tr::launch_status("tr_pixel_loss_pool_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, d->partials, nb, d->value_weight * inv, d->value_out, d->total_weight * inv, d->total_out, 0);
+    return tr::launch_status("tr_pixel_loss_pool_bwd(finish)");
 }
 
 extern "C" int tr_sumsq(void* stream, const float* x, int64_t numel, float* norm_out, float* partials) {

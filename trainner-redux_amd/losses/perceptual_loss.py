@@ -314,6 +314,8 @@ class VGG(nn.Module):
             if op[0] == "pool":
                 hh, ww = hh // 2, ww // 2
         g = None            # gradient w.r.t. the output of prog[k] (None: nothing flows from above)
+        pool_gout = None    # gradient of a pool's output whose backward is folded into the loss-gradient pass of the tapped conv below it
+        fuse_pool_bwd = not os.environ.get("TRAINNER_NO_POOL_FUSION")
         for k in range(len(prog) - 1, -1, -1):
             op = prog[k]
             hh, ww = dims[k]
@@ -323,6 +325,12 @@ class VGG(nn.Module):
                 src = ws["acts"][k - 1]                      # pool input (pre-ReLU tapped feature or post-ReLU activation)
                 pool_g = ws["g"][(hh, ww)]
                 gin = pool_g[0].view(-1)[: src.numel()].view(src.shape)
+                below = prog[k - 1]
+                if (fuse_pool_bwd and below[0] == "conv" and below[4] and src.dtype == torch.float32 and g.dtype == torch.float32 and g.is_contiguous()
+                        and src.shape[-1] % 4 == 0):
+                    pool_gout = g                            # the tapped conv below takes the pool's backward into its loss-gradient pass
+                    g = gin
+                    continue
                 ops.maxpool2x2_bwd(V(src), V(g), V(gin), n, hh, ww, True)
                 g = gin
                 continue
@@ -339,7 +347,8 @@ class VGG(nn.Module):
                 gs = 1.0 if layer_grad_scale is None else float(layer_grad_scale[name])
                 ops.pixel_loss(kind, act, ws["feats_gt"][name], value_out[j:], value_weight=value_weight * lw, total_out=total_out,
                                total_weight=total_weight * lw, grad=g if grad is not None else None, grad_weight=grad_weight * lw * gs,
-                               accumulate_grad=acc_g, eps=eps)
+                               accumulate_grad=acc_g, eps=eps, pool_gout=pool_gout)
+                pool_gout = None
             if grad is None:
                 continue
             if k == 0:

@@ -448,8 +448,10 @@ def scratch(device, nfloats: int = 4096) -> torch.Tensor:
 
 def pixel_loss(kind: int, pred: torch.Tensor, target: torch.Tensor, value_out: torch.Tensor, *, value_weight: float = 1.0,
                total_out: torch.Tensor | None = None, total_weight: float = 0.0, grad: torch.Tensor | None = None,
-               grad_weight: float | None = None, accumulate_grad: bool = False, eps: float = 1e-12):
-    """value_out[0] = value_weight*mean ; total_out[0] += total_weight*mean ; grad (+)= grad_weight * dmean/dpred."""
+               grad_weight: float | None = None, accumulate_grad: bool = False, eps: float = 1e-12, pool_gout: torch.Tensor | None = None):
+    """value_out[0] = value_weight*mean ; total_out[0] += total_weight*mean ; grad (+)= grad_weight * dmean/dpred.
+    pool_gout (n x h/2 x w/2 x c, fp32): pred (NHWC fp32) feeds max_pool2d(relu(.), 2, 2) and pool_gout is the gradient of the pool's output:
+    grad = grad_weight * dmean/dpred + max_pool2d_backward(pool_gout) through the ReLU, written once (tr_pixel_loss_pool_bwd)."""
     _need_cuda(pred, target, value_out, grad, total_out)
     assert pred.shape == target.shape and pred.dtype == target.dtype and pred.is_contiguous() and target.is_contiguous()
     assert value_out.dtype == torch.float32 and (total_out is None or total_out.dtype == torch.float32)
@@ -464,6 +466,11 @@ def pixel_loss(kind: int, pred: torch.Tensor, target: torch.Tensor, value_out: t
         assert grad.is_contiguous() and grad.numel() == pred.numel()
         d.grad, d.grad_dtype, d.accumulate_grad = grad.data_ptr(), dt_code(grad.dtype), 1 if accumulate_grad else 0
     d.partials = scratch(pred.device).data_ptr()
+    if pool_gout is not None:
+        n, h, w, c = pred.shape
+        assert grad is not None and pool_gout.is_contiguous() and pool_gout.dtype == torch.float32 and tuple(pool_gout.shape) == (n, h // 2, w // 2, c)
+        L.check(L.lib().tr_pixel_loss_pool_bwd(stream_ptr(), C.byref(d), pool_gout.data_ptr(), n, h, w, c), "tr_pixel_loss_pool_bwd")
+        return
     L.check(L.lib().tr_pixel_loss(stream_ptr(), C.byref(d)), "tr_pixel_loss")
 
 
