@@ -263,3 +263,13 @@ def test_mfma_kernels_keep_accumulators_in_registers():
         return 64 if "conv3x3_kernel_reg" in name else 0
     bad = {k: v["scratch"] for k, v in hot.items() if v.get("scratch", 0) > limit(k) or v.get("vgpr_spill", 0) > limit(k) // 4}
     assert not bad, bad
+    # Round-2 kernels.  The ring weight-gradient kernel keeps its nine accumulators and everything else in registers.  The persistent Winograd
+    # F(4,3) kernel parks tile-loop state around its epilogue (12 dwords; 39 in the masked form, which holds four mask vectors across the
+    # exchange barrier) and the generic-epilogue ring conv instances 12: all of it outside the K loops, and well below
+    # one Winograd accumulator set (6 x 16 dwords = 384 bytes) or a ring conv accumulator tile (R x NT x 16 dwords >= 256 bytes).
+    r2 = {k: v for k, v in res.items() if any(t in k for t in ("conv_ring_kernel", "wgrad_ring_kernel", "winograd43_f32_kernel"))}
+    assert len(r2) >= 40
+    def limit2(name):
+        return 0 if "wgrad_ring" in name else 96
+    bad = {k: v["scratch"] for k, v in r2.items() if v.get("scratch", 0) > limit2(k)}
+    assert not bad, bad

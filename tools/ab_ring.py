@@ -33,7 +33,7 @@ def run(impl, cfg, n, h, w, cin, cout, form, dt=torch.bfloat16, cd=L.BF16, up=Fa
 
 def mk_bufs(n, h, w, cin, cout, dt, cd, up=False):
     hi, wi = (h // 2, w // 2) if up else (h, w)
-    x = torch.randn(n, hi, wi, cin + 32, device=dev).to(dt)
+    x = torch.randn(n, hi, wi, int(os.environ.get("XS", cin + 32)), device=dev).to(dt)      # XS: channel stride of the input buffer (default cin + 32)
     wt = torch.randn(cout, cin, 3, 3, device=dev) / math.sqrt(cin * 9)
     wbuf = torch.zeros(ops.packed_bytes(cin, cout, cd), dtype=torch.uint8, device=dev)
     plan = ops.PackPlan(dev); plan.add(wt, wbuf, cin, cout, cd); plan.run()
