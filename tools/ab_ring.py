@@ -17,14 +17,15 @@ def run(impl, cfg, n, h, w, cin, cout, form, dt=torch.bfloat16, cd=L.BF16, up=Fa
     x, wbuf, bias, mk, r1, r2 = bufs
     cs = x.shape[-1]
     out_dt = torch.float32 if form in ("res1", "res2") else dt
-    out = torch.zeros(n, h, w, cout + 32, device=dev, dtype=out_dt)
+    ooff = 0 if os.environ.get("OS") else 16                                       # OS: channel stride of the output buffer (slice at 0; default cout + 32, slice at 16)
+    out = torch.zeros(n, h, w, int(os.environ.get("OS", cout + 32)), device=dev, dtype=out_dt)
     out2 = torch.zeros(n, h, w, cout, device=dev, dtype=dt)
     kw = {}
     if form == "lrelu": kw = dict(act=L.ACT_LRELU, slope=0.2)
     elif form == "mask": kw = dict(mask=ops.view(mk, 32, cout), mask_slope=0.2)
     elif form == "res1": kw = dict(res1=ops.view(r1), scale1=0.2, out2=ops.view(out2), out2_scale=0.5)
     elif form == "res2": kw = dict(res1=ops.view(r1), scale1=0.2, res2=ops.view(r2), scale2=0.2, res1_scale=0.7, out2=ops.view(out2), out2_scale=0.04)
-    f = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=cd, inp=ops.view(x, 0, cin), out=ops.view(out, 16, cout), wpacked=wbuf, bias=bias,
+    f = lambda: ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=cd, inp=ops.view(x, 0, cin), out=ops.view(out, ooff, cout), wpacked=wbuf, bias=bias,
                             in_mode=L.IN_NEAREST2X if up else L.IN_DIRECT, **kw)
     f()
     torch.cuda.synchronize()
@@ -74,6 +75,8 @@ def check():
 def bench():
     shapes = [(16, 256, 256, 64, 32), (16, 256, 256, 96, 32), (16, 256, 256, 128, 32), (16, 256, 256, 160, 32), (16, 256, 256, 192, 64),
               (16, 1024, 1024, 64, 64), (16, 512, 512, 64, 64)]
+    if os.environ.get("SHAPES"):  # e.g. SHAPES=16x256x256x32x32,16x256x256x64x32
+        shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(",")]
     if os.environ.get("N"):      # sub-batch A/B: the same layers at another batch size (does the working set fit the 256 MB Infinity Cache?)
         shapes = [(int(os.environ["N"]),) + sh[1:] for sh in shapes]
     forms = sys.argv[2].split(",") if len(sys.argv) > 2 else ["lrelu", "mask", "res1"]

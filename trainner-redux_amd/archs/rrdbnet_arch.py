@@ -221,7 +221,8 @@ class RRDBNet(FlatParamModule):
             need = max(need, ops.wgrad_workspace_bytes(n, hh, ww, cin, cout))
         ws.wg = torch.empty(need // 4 + 16, dtype=torch.float32, device=dev)
         # one more workspace per conv of a dense block: its five weight gradients go out as one launch (ops.wgrad3x3_multi)
-        ws.wg5 = [ws.wg] + [torch.empty(need // 4 + 16, dtype=torch.float32, device=dev) for _ in range(4)]
+        need5 = max(ops.wgrad_workspace_bytes(n, h, w, nf + k * gc, gc if k < 4 else nf) for k in range(5))
+        ws.wg5 = [ws.wg] + [torch.empty(need5 // 4 + 16, dtype=torch.float32, device=dev) for _ in range(4)]
 
     # ------------------------------------------------------------------ forward ---------------------
     def forward_hip(self, x: torch.Tensor, train: bool | None = None) -> torch.Tensor:
