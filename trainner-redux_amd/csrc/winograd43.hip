@@ -68,6 +68,11 @@ struct Wino43Args {
 #else
 #define Q_STAMP()
 #endif
+#if defined(TR_W43_STAMPS) && TR_W43_STAMPS >= 2
+#define Q_STAMP2() Q_STAMP()        /* epilogue detail: after the fold / DMA requests, and around each round's barriers */
+#else
+#define Q_STAMP2()
+#endif
 
 // B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1] applied to a 6-vector, two rows at a time in the
 // pairing that shares subexpressions: P = 0 -> rows (0, 5), 1 -> rows (1, 2), 2 -> rows (3, 4); 4 / 6 / 4 operations per pair.
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                         // landed when only the loads behind it in the queue are still in flight: 5 weight fragments of its own iteration +
                         // (1 + 5 DMA pieces + 5) per later iteration, less this iteration's last fragment which is requested after the barrier.
                         if (loader) {
-                            static_assert(Q_NRAW == 4, "vmcnt bookkeeping below");
+                            static_assert(Q_NRAW == 4, "vmcnt bookkeeping below; the epilogue spreads the next tile's first Q_NRAW chunks over its 4 rounds");
                             if (issued) {
                                 asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
                             } else {
@@ -331,9 +336,12 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
             }
             // the next tile's first halo chunks land during this tile's epilogue (requested here, behind the fold: a third of the accumulator
             // registers has just been freed for the offset arithmetic)
-            if (loader && tile + G < ntiles) {
+            // one chunk here, one more at the top of each later exchange round: twenty pieces per wave requested at once ran into the memory
+            // pipeline's back-pressure and held the loader waves -- and with them the first exchange barrier -- for ~9.7k ticks
+            const bool dma_next_tile = loader && tile + G < ntiles;
+            if (dma_next_tile) {
                 dma_tile(tile + G);
-                for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
+                issue_in(0, rawb);
             }
             // four exchange rounds (channel half x row pair) through [j 6][row 2][tile 32][36-float rows] = 54 KB inside the stages, so that the
             // raw buffers keep the next tile's first halo chunks; then the row fold Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte
@@ -356,9 +364,11 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
             const int pool_img = (a.h >> 1) * (a.w >> 1) * a.pool.cstride * 4;
             const __amdgpu_buffer_rsrc_t pool_rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((char*)a.pool.ptr + (int64_t)nb * pool_img + (a.pool.coff + kg * Q_KB) * 4), 0, POOL ? (unsigned)pool_img : 0u, 0x00020000);
+            Q_STAMP2()
 #pragma unroll
             for (int round = 0; round < 4; ++round) {
                 const int rkh = round >> 1, rp = round & 1;
+                if (round > 0 && dma_next_tile && round < npre) issue_in(round, rawb + round * QRAW_FLOATS);
                 // finishing threads request the round's ReLU-derivative mask values first: they arrive while the exchange goes through LDS
                 const int oy = oy0 + rp * 2;
                 u32x4 mu[4];
@@ -380,7 +390,9 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                         }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Q_STAMP2()
                 __builtin_amdgcn_s_barrier();
+                Q_STAMP2()
                 if (te < 512) {
                     const int kc = rkh * 32 + ek4;                    // channel within the workgroup's 64
                     f32x4 bias = bias2[rkh];
@@ -433,8 +445,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                         }
                     }
                 }
+                Q_STAMP2()
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+                Q_STAMP2()
             }
             Q_STAMP()
         }
