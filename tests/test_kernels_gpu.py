@@ -589,7 +589,7 @@ def test_conv3x3_split_bf16_fast_matmul(cuda, shape):
     assert rel_l2(nchw(gx.cpu()), torch.nn.grad.conv2d_input(x.shape, wt, gy, padding=1)) < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 64), (2, 20, 36, 64, 128), (1, 8, 8, 128, 64), (1, 44, 68, 8, 64), (3, 4, 4, 256, 64)])
+@pytest.mark.parametrize("shape", [(1, 16, 32, 64, 64), (2, 20, 36, 64, 128), (1, 8, 8, 128, 64), (1, 44, 68, 40, 64), (3, 4, 4, 256, 64), (3, 176, 352, 64, 64)])
 def test_winograd43_f32_forward_and_input_gradient(cuda, shape):
     """tr_conv3x3_winograd43_f32 (fused Winograd F(4x4, 3x3), fp32 MFMA): forward with bias + ReLU into a channel slice, and the input-gradient
     form (transposed slab + ReLU-derivative mask), against torch in fp64.  fp32 rounding of the 6 x 6 transforms: ~2e-6 rel-L2 per layer

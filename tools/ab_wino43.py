@@ -16,7 +16,7 @@ def rel(a, b):
 def check():
     bad = 0
     torch.manual_seed(0)
-    for (n, h, w, cin, cout) in [(1, 16, 32, 64, 64), (2, 20, 36, 64, 128), (1, 8, 8, 128, 64), (1, 44, 68, 8, 64), (3, 4, 4, 256, 64), (1, 64, 96, 72, 192)]:
+    for (n, h, w, cin, cout) in [(1, 16, 32, 64, 64), (2, 20, 36, 64, 128), (1, 8, 8, 128, 64), (1, 44, 68, 40, 64), (3, 4, 4, 256, 64), (1, 64, 96, 72, 192), (3, 176, 352, 64, 64), (3, 36, 100, 64, 128)]:
         x = torch.relu(torch.randn(n, cin, h, w, dtype=torch.float64))
         wt = torch.randn(cout, cin, 3, 3, dtype=torch.float64) * math.sqrt(2 / (cin * 9))
         b = torch.randn(cout, dtype=torch.float64)

@@ -46,7 +46,8 @@ constexpr int Q_TS = 36;                       // floats per (j, r, tile) row of
 constexpr int QX_FLOATS = 6 * 2 * Q_TB * Q_TS; // one exchange round (channel half x row pair): 55,296 B, inside the two V stages
 constexpr int QU_CHUNK = 12 * 6 * 256;         // packed U floats per (group, chunk): [wave 12][i 6][lane 64][e 4]
 constexpr int Q_NRAW = 4;                      // raw halo buffers: the DMA of chunk ch + Q_NRAW is issued while chunk ch is multiplied
-constexpr int Q_SMEM = (2 * QV_FLOATS + Q_NRAW * QRAW_FLOATS) * 4;
+constexpr int QDN_WORDS = 4 * 5 * 64;            // piece offsets of the tile after the one the halo stream is in: [loader wave 4][piece 5][lane 64]
+constexpr int Q_SMEM = (2 * QV_FLOATS + Q_NRAW * QRAW_FLOATS + QDN_WORDS) * 4;
 static_assert(QX_FLOATS <= 2 * QV_FLOATS && Q_SMEM <= 160 * 1024, "LDS budget");
 
 struct Wino43Args {
@@ -117,46 +118,97 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
     const int ntiles = a.n * a.nty * a.ntx * a.nkg;
     int first = blockIdx.x;
     if ((G & 7) == 0) first = (first & 7) * (G >> 3) + (first >> 3);
-    auto decode = [&](int t, int& kg, int& bx, int& by, int& nb) {
-        kg = t % a.nkg; t /= a.nkg;
-        bx = t % a.ntx; t /= a.ntx;
-        by = t % a.nty;
-        nb = t / a.nty;
+    // tile index -> (channel group, tile column, tile row, image): decoded once (runtime divisions cost ~50 instructions each), then advanced by the
+    // grid size digit by digit
+    struct TilePos { int kg, bx, by, nb; };
+    auto decode = [&](int t) {
+        TilePos p;
+        p.kg = t % a.nkg; t /= a.nkg;
+        p.bx = t % a.ntx; t /= a.ntx;
+        p.by = t % a.nty;
+        p.nb = t / a.nty;
+        return p;
+    };
+    const TilePos gstep = decode(G);
+    auto advance = [&](TilePos p) {                  // p + G in the mixed radix (nkg, ntx, nty, .)
+        p.kg += gstep.kg;
+        int c = p.kg >= a.nkg;
+        p.kg -= c ? a.nkg : 0;
+        p.bx += gstep.bx + c;
+        c = p.bx >= a.ntx;
+        p.bx -= c ? a.ntx : 0;
+        p.by += gstep.by + c;
+        c = p.by >= a.nty;
+        p.by -= c ? a.nty : 0;
+        p.nb += gstep.nb + c;
+        return p;
     };
 
     // ---- loader role (waves 8-11, one per SIMD; they hold no global loads or stores of the epilogue): the 18 x 34 x 8-channel halo of a chunk as
     // 1224 16-byte pieces, five LDS-DMA instructions per wave.  Only these four waves have the halo's memory latency in their (in-order) vmcnt
     // queue in front of the weight prefetches; with the loads spread over all twelve waves every wave stalled on it once per chunk at the same
-    // point and the MFMA pipe drained (-20 %).  The first Q_NRAW chunks of the NEXT tile are requested as soon as this tile's K loop has ended:
-    // they land while its epilogue runs (the exchange rounds stay inside the V stages, the raw buffers are not aliased).
+    // point and the MFMA pipe drained (-20 %).  The requests form ONE stream over (tile, chunk) that runs Q_NRAW chunks ahead of the MFMAs and
+    // does not stop at tile boundaries: the first chunks of the next tile are requested during this tile's last K iterations and land before /
+    // while its epilogue runs (the exchange rounds stay inside the V stages, the raw buffers are not aliased).  Requesting them in the epilogue
+    // instead held its first barrier for up to ~9.7k ticks (20 pieces per wave against the memory pipeline's back-pressure).  The piece offsets
+    // of a tile cost ~100 VALU with temporaries the K loop has no registers for: they are computed in the epilogue one tile ahead and parked in
+    // LDS; the stream's switch to the next tile inside the K loop is five LDS reads into the registers of the offsets it has finished with.
     const bool loader = wv >= 8;
     const int img_bytes = a.h * a.w * a.in.cstride * 4;
-    const int npre = min(a.nchunks, Q_NRAW);         // halo chunks requested ahead of a tile's K loop
+    int d_tile = first, d_ch = 0, d_buf = 0;         // halo stream: next chunk to request (tile, chunk) and the raw buffer it goes to
+    TilePos d_pos = decode(first);                   // position of d_tile ; d_pos2: of d_tile + G (whose offsets are parked in LDS)
+    TilePos d_pos2 = advance(d_pos);
     __amdgpu_buffer_rsrc_t d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.in.ptr, 0, 0, 0x00020000);
     unsigned dmaoff[5] = {Q_OOB, Q_OOB, Q_OOB, Q_OOB, Q_OOB};
-    auto dma_tile = [&](int t) {                     // loader waves: piece offsets of tile t
-        int kg, bx, by, nb;
-        decode(t, kg, bx, by, nb);
-        d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * img_bytes + a.in.coff * 4), 0, (unsigned)img_bytes, 0x00020000);
-        int le = l;                                  // opaque copy: the slot arithmetic is recomputed per tile instead of being hoisted out of the
-        asm volatile("" : "+v"(le));                 // tile loop and kept (spilled) across the K loop
+    unsigned* const dnext0 = (unsigned*)(rawb + Q_NRAW * QRAW_FLOATS) + (wv & 3) * 5 * 64;     // + k * 64 + lane
+    auto set_rsrc = [&](const TilePos& p) {
+        d_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)p.nb * img_bytes + a.in.coff * 4), 0, (unsigned)img_bytes, 0x00020000);
+    };
+    auto piece_offset = [&](const TilePos& p, int k, int le) -> unsigned {    // loader waves: buffer offset of DMA piece k of the tile at p
+        const int slot = ((wv & 3) * 5 + k) * 64 + le;
+        const int hy = slot / 68, f = slot - hy * 68;
+        const int xr = f < 18 ? 0 : f < 36 ? 1 : f < 52 ? 2 : 3;
+        const int r = f - qf_base(xr);
+        const int hx = (r >> 1) * 4 + xr, half = r & 1;
+        const int y = p.by * 16 - 1 + hy, x = p.bx * 32 - 1 + hx;
+        const bool ok = slot < QRAW_SLOTS && y >= 0 && y < a.h && x >= 0 && x < a.w;
+        return ok ? (unsigned)(((y * a.w + x) * a.in.cstride + half * 4) * 4) : Q_OOB;
+    };
+    auto park_next = [&](int k0, int k1) {           // loader waves: LDS <- offsets of pieces [k0, k1) of the tile after the stream's current one
+        if (d_tile + G < ntiles) {
+            int le = l;                              // opaque copy: the slot arithmetic is redone per call instead of being hoisted out of the tile
+            asm volatile("" : "+v"(le));             // loop and kept (spilled) across the K loop
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int slot = ((wv & 3) * 5 + k) * 64 + le;
-            const int hy = slot / 68, f = slot - hy * 68;
-            const int xr = f < 18 ? 0 : f < 36 ? 1 : f < 52 ? 2 : 3;
-            const int r = f - qf_base(xr);
-            const int hx = (r >> 1) * 4 + xr, half = r & 1;
-            const int y = by * 16 - 1 + hy, x = bx * 32 - 1 + hx;
-            const bool ok = slot < QRAW_SLOTS && y >= 0 && y < a.h && x >= 0 && x < a.w;
-            dmaoff[k] = ok ? (unsigned)(((y * a.w + x) * a.in.cstride + half * 4) * 4) : Q_OOB;
+            for (int k = 0; k < 5; ++k)
+                if (k >= k0 && k < k1) {
+                    unsigned o = piece_offset(d_pos2, k, le);
+                    dnext0[k * 64 + le] = o;
+                    asm volatile("" ::: "memory");   // one piece at a time: no array of temporaries
+                }
         }
     };
-    auto issue_in = [&](int ch, float* rb) {         // loader waves (wave-uniform), ch < nchunks
+    auto stream_issue = [&]() -> bool {              // loader waves (wave-uniform): request the next chunk of the stream, if one is left
+        if (d_tile >= ntiles) return false;
+        float* rb = rawb + d_buf * QRAW_FLOATS;
 #pragma unroll
         for (int k = 0; k < 5; ++k)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rsrc, (__attribute__((address_space(3))) void*)(rb + ((wv & 3) * 5 + k) * 256), 16, dmaoff[k],
-                                                     ch * (Q_CK * 4), 0, 0);
+                                                     d_ch * (Q_CK * 4), 0, 0);
+        d_buf = d_buf == Q_NRAW - 1 ? 0 : d_buf + 1;
+        if (++d_ch == a.nchunks) {                   // on to the next tile: its offsets were parked one epilogue ago (nchunks > Q_NRAW: host check)
+            d_ch = 0;
+            d_tile += G;
+            d_pos = d_pos2;
+            d_pos2 = advance(d_pos2);
+            if (d_tile < ntiles) {
+                set_rsrc(d_pos);
+                int le = l;
+                asm volatile("" : "+v"(le));
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dmaoff[k] = dnext0[k * 64 + le];
+            }
+        }
+        return true;
     };
 
     // ---- fill role: (tile ft, channel fc) of the chunk, one row pair of its 6 x 6 transform B^T d B (pair fp is uniform per wave and a
@@ -189,63 +241,67 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
         };
 
         f32x4 ureg[3];                                       // ring: position p lives in ureg[p % 3] and is requested two positions ahead of its MFMAs
+        int cbuf = 0;                                        // raw buffer of the next chunk (in stream order) the fill role consumes
         const int uoff = l * 4;
         {
-            int kg, bx, by, nb;
-            decode(first, kg, bx, by, nb);
-            const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256);
+            const float* ub = a.u + ((int64_t)d_pos.kg * a.nchunks * 12 + wv) * (6 * 256);
             ureg[0] = *(const f32x4*)(ub + uoff);
             ureg[1] = *(const f32x4*)(ub + 256 + uoff);
             ureg[2] = *(const f32x4*)(ub + 512 + uoff);
             asm volatile("" ::: "memory");                   // the two fragments stay in front of the halo requests in the queue, as on later tiles
             if (loader) {
-                dma_tile(first);
-                for (int c = 0; c < npre; ++c) issue_in(c, rawb + c * QRAW_FLOATS);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dmaoff[k] = piece_offset(d_pos, k, l);
+                set_rsrc(d_pos);
+                park_next(0, 5);
+                for (int c = 0; c < Q_NRAW; ++c) stream_issue();
             }
         }
+        TilePos cpos = decode(first);                        // the tile being multiplied
         for (int tile = first; tile < ntiles; tile += G) {
-            int kg, bx, by, nb;
-            decode(tile, kg, bx, by, nb);
+            const int kg = cpos.kg, bx = cpos.bx, by = cpos.by, nb = cpos.nb;
+            cpos = advance(cpos);
             // packed weights of this wave: wave-uniform base (+ chunk * QU_CHUNK + i * 256) + the lane's 4 floats
             const float* ub = a.u + ((int64_t)kg * a.nchunks * 12 + wv) * (6 * 256);
             const float* ubn = ub;                                                                // chunk 0 of the next tile (clamped at the end)
-            if (tile + G < ntiles) ubn = a.u + ((int64_t)((tile + G) % a.nkg) * a.nchunks * 12 + wv) * (6 * 256);
+            if (tile + G < ntiles) ubn = a.u + ((int64_t)cpos.kg * a.nchunks * 12 + wv) * (6 * 256);
             f32x16 acc[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-            // ---- V of chunk 0.  The queue of a loader wave holds [3 weight fragments, npre halo chunks of 5 pieces] at this point (loads retire
-            // in order): chunk 0 has landed when only the later chunks are in flight
-            if (loader) {
-                if (npre == 4) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                else if (npre == 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else if (npre == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- V of chunk 0.  First tile: the queue of a loader wave holds [3 weight fragments, Q_NRAW halo chunks of 5 pieces] (loads retire in
+            // order): chunk 0 has landed when only the later chunks are in flight.  Later tiles: their first chunks were requested during the
+            // previous tile's last K iterations and checked off there (the loop's rule: two chunks ahead have landed at every chunk barrier), and
+            // every wave has passed the previous epilogue's last barrier.
+            if (tile == first) {
+                if (loader) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_s_barrier();
             Q_STAMP()
+            {
+                const float* rb0 = rawb + cbuf * QRAW_FLOATS;
+                cbuf = cbuf == Q_NRAW - 1 ? 0 : cbuf + 1;
 #pragma unroll
-            for (int c = 0; c < 6; ++c) fill_col(rawb, c);
+                for (int c = 0; c < 6; ++c) fill_col(rb0, c);
 #pragma unroll
-            for (int pr = 0; pr < 3; ++pr) fill_out(vst, pr);
-            if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the other chunks requested ahead
+                for (int pr = 0; pr < 3; ++pr) fill_out(vst, pr);
+            }
+            if (tile == first && loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the other chunks requested up front
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             Q_STAMP()
-            int rnext = 1 % Q_NRAW;                          // raw buffer of chunk ch + 1
             f32x4 bv[2];
             bv[0] = *(const f32x4*)(vst + (lh * Q_TB + lr) * 4 + wj * 256);
             for (int ch = 0; ch < a.nchunks; ++ch) {
                 const float* vl = vst + (ch & 1) * QV_FLOATS + (lh * Q_TB + lr) * 4;          // + xi * 256
                 float* nst = vst + ((ch + 1) & 1) * QV_FLOATS;
-                const float* rb = rawb + rnext * QRAW_FLOATS;
-                const int rfree = rnext == 0 ? Q_NRAW - 1 : rnext - 1;                        // buffer of chunk ch: consumed an iteration ago
-                rnext = rnext == Q_NRAW - 1 ? 0 : rnext + 1;
+                const float* rb = rawb + cbuf * QRAW_FLOATS;                                  // raw halo of the next chunk in stream order
+                if (ch + 1 < a.nchunks) cbuf = cbuf == Q_NRAW - 1 ? 0 : cbuf + 1;             // (a tile's last chunk builds an unused stage from it)
                 const float* uc = ub + (int64_t)ch * QU_CHUNK;
                 const float* un = ch + 1 < a.nchunks ? uc + QU_CHUNK : ubn;
-                const bool issued = ch + Q_NRAW < a.nchunks;
+                bool issued = false;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     if (i == 5) {
@@ -300,11 +356,10 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                         fill_out(nst, i - 2);
                     }
 #endif
-                    // chunk ch + Q_NRAW goes to the raw buffer whose chunk (the one being multiplied) was consumed an iteration ago: two whole
-                    // chunks of lead (a halo chunk is 4-5 us away under load: start -> first halo landed = 11-15k ticks in the
-                    // stamps; one chunk of lead was short of it on every fourth chunk, the one that opens a new 128-byte line of the pixel
-                    // records; a fourth buffer measured no further gain)
-                    if (i == 0 && loader && issued) issue_in(ch + Q_NRAW, rawb + rfree * QRAW_FLOATS);
+                    // the stream's next chunk (Q_NRAW ahead of the one being multiplied, possibly in the next tile) goes to the raw buffer whose
+                    // chunk -- this one -- was consumed an iteration ago: three chunks of lead (a halo chunk is 4-5 us away under load: start ->
+                    // first halo landed = 11-15k ticks in the stamps)
+                    if (i == 0 && loader) issued = stream_issue();
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -336,13 +391,6 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
             }
             // the next tile's first halo chunks land during this tile's epilogue (requested here, behind the fold: a third of the accumulator
             // registers has just been freed for the offset arithmetic)
-            // one chunk here, one more at the top of each later exchange round: twenty pieces per wave requested at once ran into the memory
-            // pipeline's back-pressure and held the loader waves -- and with them the first exchange barrier -- for ~9.7k ticks
-            const bool dma_next_tile = loader && tile + G < ntiles;
-            if (dma_next_tile) {
-                dma_tile(tile + G);
-                issue_in(0, rawb);
-            }
             // four exchange rounds (channel half x row pair) through [j 6][row 2][tile 32][36-float rows] = 54 KB inside the stages, so that the
             // raw buffers keep the next tile's first halo chunks; then the row fold Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte
             // stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).  Raw barriers with LDS-only waits: the stores drain behind.
@@ -368,16 +416,16 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
 #pragma unroll
             for (int round = 0; round < 4; ++round) {
                 const int rkh = round >> 1, rp = round & 1;
-                if (round > 0 && dma_next_tile && round < npre) issue_in(round, rawb + round * QRAW_FLOATS);
                 // finishing threads request the round's ReLU-derivative mask values first: they arrive while the exchange goes through LDS
                 const int oy = oy0 + rp * 2;
                 u32x4 mu[4];
-                if (MASK && te < 512) {
-#pragma unroll
-                    for (int sx = 0; sx < 4; ++sx) {
-                        const bool ok = oy < a.h && ox0 + sx < a.w;
-                        mu[sx] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, ok ? ((oy * a.w + ox0 + sx) * a.mask.cstride + rkh * 32 + ek4) * 4 : (int)Q_OOB, 0, 0);
-                    }
+                auto mask_load = [&](int sx) {
+                    const bool ok = oy < a.h && ox0 + sx < a.w;
+                    mu[sx] = __builtin_amdgcn_raw_buffer_load_b128(mask_rsrc, ok ? ((oy * a.w + ox0 + sx) * a.mask.cstride + rkh * 32 + ek4) * 4 : (int)Q_OOB, 0, 0);
+                };
+                if (MASK && te < 512) {                               // (two of the four: all four cost the K loop its last registers)
+                    mask_load(0);
+                    mask_load(1);
                 }
                 if (wkh == rkh) {
 #pragma unroll
@@ -393,7 +441,15 @@ __global__ __launch_bounds__(Q_THREADS, 1) void winograd43_f32_kernel(Wino43Args
                 Q_STAMP2()
                 __builtin_amdgcn_s_barrier();
                 Q_STAMP2()
+                // loader waves (which finish nothing: threads >= 512, and write nothing in the first two rounds) use those rounds' finishing phases
+                // to park the piece offsets of the tile after the stream's current one
+                if (round == 0 && loader) park_next(0, 3);
+                if (round == 1 && loader) park_next(3, 5);
                 if (te < 512) {
+                    if (MASK) {
+                        mask_load(2);
+                        mask_load(3);
+                    }
                     const int kc = rkh * 32 + ek4;                    // channel within the workgroup's 64
                     f32x4 bias = bias2[rkh];
                     if (MASK && a.bias) bias = *(const f32x4*)(a.bias + kg * Q_KB + kc);
@@ -505,8 +561,8 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     TR_REQUIRE(d != nullptr, TR_EINVAL, "tr_conv3x3_winograd43_f32: null descriptor");
     TR_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->h % 4 == 0 && d->w % 4 == 0, TR_EUNSUPPORTED,
                "tr_conv3x3_winograd43_f32: needs output dims that are multiples of 4 (got %dx%d)", d->h, d->w);
-    TR_REQUIRE(d->cin > 0 && d->cin % Q_CK == 0 && d->cout > 0 && d->cout % Q_KB == 0, TR_EUNSUPPORTED,
-               "tr_conv3x3_winograd43_f32: cin=%d must be a multiple of %d and cout=%d of %d", d->cin, Q_CK, d->cout, Q_KB);
+    TR_REQUIRE(d->cin > Q_NRAW * Q_CK && d->cin % Q_CK == 0 && d->cout > 0 && d->cout % Q_KB == 0, TR_EUNSUPPORTED,
+               "tr_conv3x3_winograd43_f32: cin=%d must be a multiple of %d above %d and cout=%d a multiple of %d", d->cin, Q_CK, Q_NRAW * Q_CK, d->cout, Q_KB);
     TR_REQUIRE(d->ksize == 3 && d->in_mode == TR_IN_DIRECT && d->pad_mode == TR_PAD_ZEROS, TR_EUNSUPPORTED,
                "tr_conv3x3_winograd43_f32: 3x3, direct input, zero padding only");
     TR_REQUIRE(d->act == TR_ACT_NONE || d->act == TR_ACT_RELU, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: activation %d is not built (none, ReLU)", d->act);

@@ -100,7 +100,7 @@ def pack_winograd(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor
 
 
 def winograd43_eligible(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 8 == 0 and cout % 64 == 0 and h % 4 == 0 and w % 4 == 0
+    return cin % 8 == 0 and cin > 32 and cout % 64 == 0 and h % 4 == 0 and w % 4 == 0      # more than four 8-channel chunks: the halo stream's lookahead
 
 
 def pack_winograd43(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
