@@ -4,17 +4,20 @@
 // the MFMA cycles of the F(2x2, 3x3) kernel (winograd.hip) and 0.25 of the direct form, at ~2e-6 relative error per layer in fp32 (F(2x2): 4e-7,
 // direct: 2e-7; measured against fp64 on VGG-shaped layers) -- every operation is an fp32 add / multiply / MFMA.
 //
-// Workgroup = 768 threads = 12 waves, one per CU; tile = 64 output channels x 32 Winograd tiles (4 x 8 tiles = 16 x 32 output pixels).
+// Workgroups of 768 threads = 12 waves, one per CU, PERSISTENT over tiles of 64 output channels x 32 Winograd tiles (4 x 8 tiles = 16 x 32 output
+// pixels); ids are dealt so that the workgroups of an XCD walk consecutive tiles (the channel groups of a patch share its input in one L2).
 // Wave (j, kh) owns column j of the 6 x 6 positions for output-channel half kh: six 32 x 32 accumulators (channel x tile), so the column fold
-// A^T M[:, j] of the output transform is register arithmetic.  K loop over 8-channel chunks, one barrier per chunk:
+// A^T M[:, j] of the output transform is register arithmetic.  K loop over 8-channel chunks, one barrier per chunk (in front of position 5):
 //   * the transformed weights U never touch LDS: no two waves share an element, so a wave fetches the A fragments of its six positions straight
-//     from the packed array (16 bytes per lane and position, contiguous over the wave) and re-loads each position's registers for the next chunk
-//     right after its MFMAs (a rolling prefetch with a whole chunk of lead, no second register set);
-//   * only V = B^T d B goes through LDS (two 36 KB stages): the 18 x 34 x 8-channel halo of a chunk is fetched once per workgroup with 16-byte
-//     loads (three chunks in flight: loads of ch + 3, raw halo of ch + 2 in LDS, V of ch + 1, MFMAs on ch) and thread (tile, channel, row pair)
-//     builds two of the six rows of its 6 x 6 patch transform, one patch column behind each position's MFMAs;
-//   * epilogue: column fold in registers, one exchange round per channel half through LDS ([j][r][tile][36-float rows]), row fold
-//     Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask, 16-byte stores (8 lanes = the 128 contiguous bytes of a pixel's 32 channels).
+//     from the packed array (16 bytes per lane and position, contiguous over the wave) into a three-position register ring, two positions ahead;
+//   * the raw 18 x 34 x 8-channel halo of a chunk goes global -> LDS by buffer_load ... lds from four loader waves (8-11), four buffers, one request
+//     stream over (tile, chunk) that runs four chunks ahead and through the epilogues; only V = B^T d B is computed into LDS (two 36 KB stages):
+//     thread (tile, channel, row pair) builds two of the six rows of its 6 x 6 patch transform (compile-time pairs with shared subexpressions:
+//     the K loop exists once per pair), spread behind the MFMAs of positions 0-4;
+//   * epilogue: column fold in registers (in place), four exchange rounds (channel half x row pair) through [j][r][tile][36-float rows] inside
+//     the V stages, row fold Y[r][:] = T[r] A, bias / ReLU / ReLU-derivative mask / optional 2 x 2 max pool, 16-byte buffer stores (8 lanes =
+//     the 128 contiguous bytes of a pixel's 32 channels).
+// What bounded each step of this structure, measured with the in-kernel stamps: DESIGN.md section 4.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
