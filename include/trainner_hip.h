@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 1
+#define TR_ABI_VERSION 2   /* 2: tr_tune_set / tr_tune_get; tr_adamw_ema skips the update on the device when *grad_norm is not finite */
 
 enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2, TR_BF16X3 = 3 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
@@ -53,6 +53,15 @@ typedef struct tr_view {
 
 int         tr_abi_version(void);
 const char* tr_last_error(void);
+/* Kernel-selection switches (no reference counterpart: cuDNN picks its algorithms behind torch.backends.cudnn.benchmark, train.py:276-283).
+ * Keys: "conv_impl" (0 automatic | 1 register-staged kernels | 2 LDS-DMA ring kernel whenever eligible), "ring_cfg" (-1 automatic | 33 / 32 / 31 |
+ * 0), "ring_generic" (0 | 1), "wgrad_impl" (0 | 1 | 2), "wgrad_multi" (1 | 0), "dgrad_image_ref" (0 | 1); read-only records of the last
+ * tr_conv3x3 launch: "last_conv_family" (1 register-staged, 2 LDS-DMA two-stage, 3 token GEMM, 4 ring), "last_conv_instance", and the counter "ring_launches".  Initial values
+ * come from the TRAINNER_* environment variables once, at load time; launches never read the environment.  Process-wide, not thread-safe
+ * against concurrent launches (the step is driven by one host thread, SURVEY.md section 8b "Threading").
+ * tr_tune_set returns TR_EINVAL for an unknown key; tr_tune_get returns -1 and sets tr_last_error(). */
+int         tr_tune_set(const char* key, long long value);
+long long   tr_tune_get(const char* key);
 /* number of bytes of packed weights for a (cin, cout) 3x3 conv in `compute` dtype */
 size_t      tr_conv3x3_packed_bytes(int cin, int cout, int compute);
 /* same for a ksize x ksize kernel (ksize = 1: token GEMMs, i.e. nn.Linear over an NHWC token grid) */

@@ -1,0 +1,393 @@
+"""Parity of the persistent LDS-DMA ring kernel (`conv_ring_kernel`, csrc/conv_ring.hip) -- the kernel every 16-bit 3x3 convolution of the
+ESRGAN trunk / upsampling tail runs on at bench sizes -- against plain PyTorch fp32 on the CPU (`F.conv2d` / `conv2d_input` on the same
+rounded operands).  Reference arithmetic: /root/reference/traiNNer/archs/scunet_aaf6aa_arch.py:310-384 (dense convs + LeakyReLU(0.2),
+`x5*0.2 + x`, `out*0.2 + x`, nearest x2 -> conv -> LeakyReLU) and autograd's conv backward of the same (sr_model.py:681).
+
+The automatic selection only takes this kernel from 2^17 pixels per launch upwards; `tr_tune_set("conv_impl", 2)` makes it take every
+eligible launch, so that small ragged shapes reach each template instance:
+  * 32-wide output group, resident weights, pipelined epilogue, ring depth 3 / 2 / 1   (ring_cfg 33 / 32 / 31; cin <= 128)
+  * 32-wide, streamed weights, 16-row tiles                                            (ring_cfg 0, and cin >= 160)
+  * 64-wide output groups (cout > 32), streamed weights
+and each epilogue form: fast forms 0 (plain / LeakyReLU), 1 (sign mask: input gradient), 2 (one or two fp32 residuals + second output)
+and the generic body 3 / 4 / 5 (ReLU, fp32 output, fp32 mask, second output next to a mask, cout % 32 != 0, `ring_generic`).
+Every case asserts that the ring kernel (not the register-staged one) served the launch.
+
+Tolerances (as tests/test_kernels_gpu.py): fp32 output of 16-bit-representable operands: rel-L2 <= 2e-6 (summation order only);
+16-bit output: <= 1e-3 against the reference rounded the same way (BASELINE.json north_star's bf16 tolerance; measured ~1e-5: rare 1-ulp
+flips) and >= 99 % of the elements bit-identical.
+"""
+import math
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _ct(L, name):
+    if name == "bf16":
+        return L.BF16, torch.bfloat16
+    return L.F16, torch.float16
+
+
+def _rnd(t, dt):
+    return t.to(dt).to(torch.float32)
+
+
+def _pack(ops, w, cin, cout, compute, dev, transpose=False):
+    buf = torch.zeros(ops.packed_bytes(cin, cout, compute), dtype=torch.uint8, device=dev)
+    plan = ops.PackPlan(dev)
+    plan.add(w, buf, cin, cout, compute, transpose=transpose)
+    plan.run()
+    return buf
+
+
+def _check16(got, ref, dt, what):
+    """16-bit output against the fp32 reference rounded the same way."""
+    refr = _rnd(ref, dt)
+    e = rel_l2(got, refr)
+    same = (got == refr).float().mean().item()
+    assert e < 1e-3 and same > 0.99, (what, e, same)
+
+
+def _ring(ops, expect_instance=None):
+    fam = ops.last_conv_family()
+    inst = ops.tune_get("last_conv_instance")
+    assert fam == "ring", f"the launch was served by '{fam}', not by the ring kernel"
+    if expect_instance is not None:
+        assert inst == expect_instance, (inst, expect_instance)
+    return inst
+
+
+# (n, h, w): one tile and less; ragged in both directions against the 32-wide x 8- or 16-row tiles; several tiles per image
+GEOMS = [(1, 17, 33), (2, 40, 72), (1, 9, 100), (3, 16, 32)]
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("chan", [(64, 32, -1), (96, 32, -1), (128, 32, -1), (64, 32, 32), (96, 32, 31), (128, 32, 0), (160, 32, -1), (192, 64, -1), (64, 64, -1),
+                                  (64, 128, -1)])
+def test_ring_forward_lrelu_dense_slice(cuda, compute_name, geom, chan):
+    """RDB conv1-4 / conv of the tail: bias + LeakyReLU(0.2), 16-bit output into the next channel slice of the SAME 192(+)-channel buffer the
+    input is a prefix of (in-place torch.cat, scunet_aaf6aa_arch.py:328-334) -- fast epilogue form 0."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w = geom
+    cin, cout, cfg = chan
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(100 + cin + cout + h)
+    ctot = cin + cout + 32
+    buf = _rnd(torch.randn(n, h, w, ctot, generator=g), dt)
+    wt = _rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dt)
+    b = torch.randn(cout, generator=g)
+    ref = F.leaky_relu(F.conv2d(nchw(buf[..., :cin]), wt, b, padding=1), 0.2)
+    bd, bias = buf.to(cuda, dt), b.to(cuda)
+    wp = _pack(ops, wt.to(cuda), cin, cout, compute, cuda)
+    with ops.tuned(conv_impl=2, ring_cfg=cfg):
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(bd, 0, cin), out=ops.view(bd, cin, cout), wpacked=wp, bias=bias,
+                    act=L.ACT_LRELU, slope=0.2)
+    inst = _ring(ops)
+    assert inst % 10 == 0                                      # fast form 0
+    if cout <= 32:
+        depth, wres, rows = inst // 100 % 10, inst // 10 % 10, inst // 1000 % 10
+        if cfg == 0 or cin >= 160:
+            assert wres == 0 and rows == 4, inst                                        # streamed weights, 16-row tiles
+        else:
+            assert wres == 1 and rows == 2 and depth <= {-1: 3, 32: 2, 31: 1}[cfg], inst  # resident weights, pipelined 8-row tiles, the deepest ring that fits LDS
+    else:
+        assert inst // 10000 == 2, inst                        # 64-wide groups
+    got = bd.float().cpu()
+    _check16(nchw(got[..., cin:cin + cout]), ref, dt, (geom, chan))
+    assert torch.equal(got[..., :cin], buf[..., :cin]) and torch.equal(got[..., cin + cout:], buf[..., cin + cout:])      # neighbours untouched
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    # (geom, cin, cout, ring_cfg, act, out fp32?, second output?, generic forced?)
+    ((2, 40, 72), 64, 32, -1, "relu", False, False, False),      # ReLU: generic body
+    ((1, 17, 33), 96, 32, -1, "lrelu", True, False, False),      # fp32 output: generic body
+    ((2, 40, 72), 128, 32, 0, "none", True, True, False),        # fp32 output + 16-bit second output, no side input: generic
+    ((1, 9, 100), 64, 24, -1, "lrelu", False, False, False),     # cout % 32 != 0 (8 | cout): generic, partial channel group
+    ((1, 17, 33), 192, 40, -1, "none", True, False, False),      # 64-wide group, 40 real channels
+    ((2, 40, 72), 64, 32, -1, "lrelu", False, False, True),      # fast-eligible shape through the generic body (A/B switch)
+    ((1, 33, 64), 160, 32, -1, "lrelu", False, False, True),
+    ((1, 17, 33), 64, 64, -1, "none", False, False, True),
+])
+def test_ring_forward_generic_epilogue(cuda, compute_name, case):
+    from trainner_redux_amd import _lib as L, ops
+
+    (n, h, w), cin, cout, cfg, act, out32, second, generic = case
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = _rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dt)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    ref = F.relu(ref) if act == "relu" else F.leaky_relu(ref, 0.2) if act == "lrelu" else ref
+    xd, bias = nhwc(x).to(cuda, dt), b.to(cuda)
+    wp = _pack(ops, wt.to(cuda), cin, cout, compute, cuda)
+    cpad = (cout + 7) // 8 * 8 + 8
+    out = torch.full((n, h, w, cpad), 3.0, dtype=torch.float32 if out32 else dt, device=cuda)
+    out2 = torch.full((n, h, w, cpad), 5.0, dtype=dt, device=cuda) if second else None
+    with ops.tuned(conv_impl=2, ring_cfg=cfg, ring_generic=int(generic)):
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out, 8, cout), wpacked=wp, bias=bias,
+                    act={"relu": L.ACT_RELU, "lrelu": L.ACT_LRELU, "none": L.ACT_NONE}[act], slope=0.2,
+                    **(dict(out2=ops.view(out2, 0, cout), out2_scale=0.5) if second else {}))
+    assert _ring(ops) % 10 == 3                                # generic body, no side input
+    got = out.float().cpu()
+    if out32:
+        assert rel_l2(nchw(got[..., 8:8 + cout]), ref) < 2e-6
+    else:
+        _check16(nchw(got[..., 8:8 + cout]), ref, dt, case)
+    assert torch.all(got[..., :8] == 3.0) and torch.all(got[..., 8 + cout:] == 3.0)
+    if second:
+        g2 = out2.float().cpu()
+        _check16(nchw(g2[..., :cout]), ref * 0.5, dt, case)
+        assert torch.all(g2[..., cout:] == 5.0)
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    # (geom, g channels (launch cin), x channels (launch cout), ring_cfg, out fp32?, mask fp32?, second output?, generic forced?)
+    ((2, 40, 72), 64, 32, -1, False, False, False, False),       # x4's gradient: fast form 1, resident weights + LDS-staged mask tile
+    ((1, 17, 33), 96, 32, -1, False, False, False, False),
+    ((1, 9, 100), 128, 32, -1, False, False, False, False),
+    ((3, 16, 32), 96, 32, 32, False, False, False, False),       # ring depth 2 / 1: one or two mask-tile buffers
+    ((2, 40, 72), 64, 32, 31, False, False, False, False),
+    ((1, 17, 33), 160, 32, -1, False, False, False, False),      # streamed weights
+    ((2, 40, 72), 128, 32, 0, False, False, False, False),
+    ((1, 33, 64), 64, 64, -1, False, False, False, False),       # 64-wide: HR conv's input gradient with the LeakyReLU mask of the layer below
+    ((2, 40, 72), 96, 32, -1, True, False, False, False),        # fp32 output: generic body 4
+    ((1, 17, 33), 64, 32, -1, False, True, False, False),        # fp32 mask: generic
+    ((1, 17, 33), 64, 64, -1, True, False, True, False),         # fp32 out + second output next to a mask: generic
+    ((2, 40, 72), 64, 32, -1, False, False, False, True),        # fast-eligible through the generic body
+])
+def test_ring_input_gradient_with_sign_mask(cuda, compute_name, case):
+    """The input gradient of a dense conv = the same kernel on the transposed / flipped slab; LeakyReLU's derivative is an epilogue mask taken from
+    the saved activation (the sign of x_k): fast form 1 and the generic body 4."""
+    from trainner_redux_amd import _lib as L, ops
+
+    (n, h, w), cg, cx, cfg, out32, mask32, second, generic = case
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(50 + cg + cx + h)
+    wt = _rnd(torch.randn(cg, cx, 3, 3, generator=g) / math.sqrt(cg * 9), dt)        # OIHW of the forward conv x (cx) -> y (cg)
+    gy = _rnd(torch.randn(n, cg, h, w, generator=g), dt)
+    pre = torch.randn(n, cx, h, w, generator=g)
+    pre = pre if mask32 else _rnd(pre, dt)
+    ref = torch.nn.grad.conv2d_input((n, cx, h, w), wt, gy, padding=1) * torch.where(pre > 0, 1.0, 0.2)
+    wp = _pack(ops, wt.to(cuda), cg, cx, compute, cuda, transpose=True)
+    gyd = nhwc(gy).to(cuda, dt)
+    pred = nhwc(pre).to(cuda, torch.float32 if mask32 else dt)
+    out = torch.full((n, h, w, cx + 8), 3.0, dtype=torch.float32 if out32 else dt, device=cuda)
+    out2 = torch.full((n, h, w, cx), 5.0, dtype=dt, device=cuda) if second else None
+    with ops.tuned(conv_impl=2, ring_cfg=cfg, ring_generic=int(generic)):
+        ops.conv3x3(n=n, h=h, w=w, cin=cg, cout=cx, compute=compute, inp=ops.view(gyd), out=ops.view(out, 0, cx), wpacked=wp, mask=ops.view(pred),
+                    mask_slope=0.2, **(dict(out2=ops.view(out2), out2_scale=0.04) if second else {}))
+    inst = _ring(ops)
+    assert inst % 10 == (4 if (out32 or mask32 or second or generic) else 1), inst
+    got = out.float().cpu()
+    if out32:
+        assert rel_l2(nchw(got[..., :cx]), ref) < 2e-6
+    else:
+        _check16(nchw(got[..., :cx]), ref, dt, case)
+    assert torch.all(got[..., cx:] == 3.0)
+    if second:
+        _check16(nchw(out2.float().cpu()), ref * 0.04, dt, case)
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("case", [
+    # (geom, cin, two residuals?, second output?, act, generic forced?)
+    ((2, 40, 72), 192, True, True, "none", False),       # RDB3's conv5: (conv*0.2 + x)*0.2 + rrdb_in, fp32 stream + 16-bit copy: fast form 2
+    ((1, 17, 33), 192, False, True, "none", False),      # RDB1/2's conv5
+    ((1, 9, 100), 192, True, False, "none", False),
+    ((3, 16, 32), 64, False, False, "none", False),      # trunk conv + long skip
+    ((1, 33, 64), 192, True, True, "lrelu", False),      # an activation before the residuals: generic body 5
+    ((2, 40, 72), 192, True, True, "none", True),
+])
+def test_ring_conv5_residual_streams(cuda, compute_name, case):
+    """`x5*0.2 + x` then `out*0.2 + x` (scunet_aaf6aa_arch.py:334-336,355-360): fp32 residual inputs, fp32 output (the residual stream) and the
+    compute-dtype copy that feeds the next block's MFMA operand, written into a slice of the next block's buffer."""
+    from trainner_redux_amd import _lib as L, ops
+
+    (n, h, w), cin, two, second, act, generic = case
+    cout = 64
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(3 + cin + h)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = _rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dt)
+    b = torch.randn(cout, generator=g)
+    r1 = torch.randn(n, cout, h, w, generator=g)
+    r2 = torch.randn(n, cout, h, w, generator=g)
+    v = F.conv2d(x, wt, b, padding=1)
+    if act == "lrelu":
+        v = F.leaky_relu(v, 0.2)
+    ref = v * 0.2 + r1
+    if two:
+        ref = ref * 0.2 + r2
+    xd, bias, r1d, r2d = nhwc(x).to(cuda, dt), b.to(cuda), nhwc(r1).to(cuda), nhwc(r2).to(cuda)
+    wp = _pack(ops, wt.to(cuda), cin, cout, compute, cuda)
+    out = torch.empty(n, h, w, cout, dtype=torch.float32, device=cuda)
+    nxt = torch.full((n, h, w, 192), 5.0, dtype=dt, device=cuda) if second else None
+    kw = dict(res1=ops.view(r1d), scale1=0.2)
+    if two:
+        kw.update(res2=ops.view(r2d), scale2=0.2)
+    if second:
+        kw.update(out2=ops.view(nxt, 0, cout), out2_scale=1.0)
+    with ops.tuned(conv_impl=2, ring_generic=int(generic)):
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bias,
+                    act=L.ACT_LRELU if act == "lrelu" else L.ACT_NONE, slope=0.2, **kw)
+    inst = _ring(ops)
+    assert inst % 10 == (5 if (act != "none" or generic) else 2) and inst // 10000 == 2, inst
+    assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+    if second:
+        got2 = nxt.float().cpu()
+        _check16(nchw(got2[..., :cout]), ref, dt, case)
+        assert torch.all(got2[..., cout:] == 5.0)
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+def test_ring_backward_conv5_gradient_forms(cuda, compute_name):
+    """The input gradient of conv5 in the mirrored dense layout (archs/rrdbnet_arch.py backward_hip): 192-channel gradient buffer in, fp32
+    gradient stream out with `res1_scale` / two residuals and a scaled 16-bit copy into the next block's gradient buffer."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w = 2, 24, 40
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(19)
+    gbuf = _rnd(torch.randn(n, 192, h, w, generator=g), dt)
+    wt = _rnd(torch.randn(192, 64, 3, 3, generator=g) / 40, dt)      # stands for the concatenated transposed slab: OIHW x(64) -> G(192)
+    r1 = torch.randn(n, 64, h, w, generator=g)
+    r2 = torch.randn(n, 64, h, w, generator=g)
+    conv = torch.nn.grad.conv2d_input((n, 64, h, w), wt, gbuf, padding=1)
+    wp = _pack(ops, wt.to(cuda), 192, 64, compute, cuda, transpose=True)
+    gd, r1d, r2d = nhwc(gbuf).to(cuda, dt), nhwc(r1).to(cuda), nhwc(r2).to(cuda)
+    for kind in ("r3", "r1"):
+        out = torch.empty(n, h, w, 64, dtype=torch.float32, device=cuda)
+        nxt = torch.zeros(n, h, w, 192, dtype=dt, device=cuda)
+        if kind == "r3":
+            kw = dict(res1=ops.view(r1d), res1_scale=0.2, out2=ops.view(nxt, 0, 64), out2_scale=0.2)
+            ref = conv + 0.2 * r1
+            ref2 = ref * 0.2
+        else:
+            kw = dict(res1=ops.view(r1d), res2=ops.view(r2d), out2=ops.view(nxt, 0, 64), out2_scale=0.04)
+            ref = conv + r1 + r2
+            ref2 = ref * 0.04
+        with ops.tuned(conv_impl=2):
+            ops.conv3x3(n=n, h=h, w=w, cin=192, cout=64, compute=compute, inp=ops.view(gd), out=ops.view(out), wpacked=wp, **kw)
+        assert _ring(ops) % 10 == 2
+        assert rel_l2(nchw(out.cpu()), ref) < 2e-6, kind
+        _check16(nchw(nxt.float().cpu()[..., :64]), ref2, dt, kind)
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("geom", [(1, 10, 18), (2, 20, 36), (1, 7, 50)])
+def test_ring_nearest2x_and_replicate(cuda, compute_name, geom):
+    """nn.Upsample(nearest x2) fused into the halo load (scunet_aaf6aa_arch.py:371-377), and replicate padding (VGG conv1_1's rule,
+    perceptual_fp16_loss.py:272-274, when the 16-bit head `perceptualfp16loss` runs a 64-channel layer this way)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w = geom
+    c = 64
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(11 + h)
+    x = _rnd(torch.randn(n, c, h, w, generator=g), dt)
+    wt = _rnd(torch.randn(c, c, 3, 3, generator=g) / 24, dt)
+    b = torch.randn(c, generator=g)
+    wp = _pack(ops, wt.to(cuda), c, c, compute, cuda)
+    xd, bias = nhwc(x).to(cuda, dt), b.to(cuda)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1), 0.2)
+    out = torch.empty(n, 2 * h, 2 * w, c, dtype=dt, device=cuda)
+    with ops.tuned(conv_impl=2):
+        ops.conv3x3(n=n, h=2 * h, w=2 * w, cin=c, cout=c, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bias, act=L.ACT_LRELU,
+                    slope=0.2, in_mode=L.IN_NEAREST2X)
+    _ring(ops)
+    _check16(nchw(out.float().cpu()), ref, dt, "nearest2x")
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), wt, b)
+    out = torch.empty(n, h, w, c, dtype=torch.float32, device=cuda)
+    with ops.tuned(conv_impl=2):
+        ops.conv3x3(n=n, h=h, w=w, cin=c, cout=c, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bias, pad_mode=L.PAD_REPLICATE)
+    _ring(ops)
+    assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+def test_ring_matches_register_kernel_bit_for_bit(cuda, compute_name):
+    """conv_ring.hip's header: same slabs, same MFMA orientation and accumulation order as conv3x3_kernel_reg -> identical bits.  (This is a
+    HIP-vs-HIP statement on top of the F.conv2d parity above, at a size where the automatic selection itself switches kernels.)"""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute, dt = _ct(L, compute_name)
+    n, h, w, cin, cout = 2, 256, 288, 96, 32          # 147,456 pixels >= 2^17: the automatic selection takes the ring kernel
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, h, w, cin, generator=g).to(cuda, dt)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 30).to(cuda)
+    b = torch.randn(cout, generator=g).to(cuda)
+    wp = _pack(ops, wt, cin, cout, compute, cuda)
+    outs = {}
+    for impl in (0, 1):
+        out = torch.empty(n, h, w, cout, dtype=dt, device=cuda)
+        with ops.tuned(conv_impl=impl):
+            ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(x), out=ops.view(out), wpacked=wp, bias=b, act=L.ACT_LRELU)
+        assert ops.last_conv_family() == ("ring" if impl == 0 else "reg")
+        outs[impl] = out.float().cpu()
+    assert torch.equal(outs[0], outs[1])
+    # and a row band of it against the CPU reference (full conv of 147k pixels x 96 channels is cheap enough to do whole)
+    ref = F.leaky_relu(F.conv2d(nchw(x.float().cpu()), _rnd(wt.cpu(), dt), b.cpu(), padding=1), 0.2)
+    _check16(nchw(outs[0]), ref, dt, "auto-selected ring")
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+def test_rrdb_block_at_ring_size_against_oracle(cuda, compute_name):
+    """One RRDB (15 dense convs, 3 + 1 scaled residual adds) + trunk conv + HR conv + conv_last, fed the oracle's input at a size where the
+    AUTOMATIC selection puts every 16-bit conv on the ring kernel (1 x 3 x 360 x 376 = 135,360 pixels, ragged against the 32 x 16 tiles):
+    forward and every parameter gradient against oracle/esrgan.py under the same precision policy (bf16 / f16 MFMA operands, fp32 everything
+    else).  Arithmetic: scunet_aaf6aa_arch.py:310-360."""
+    from collections import OrderedDict
+
+    from oracle import esrgan as OE
+    from oracle.precision import BF16_OPS, F16_OPS
+    from trainner_redux_amd import ops
+    from trainner_redux_amd.archs import build_network
+
+    dt = torch.bfloat16 if compute_name == "bf16" else torch.float16
+    policy = BF16_OPS if compute_name == "bf16" else F16_OPS
+    kw = dict(scale=1, use_pixel_unshuffle=False, num_blocks=1)
+    hp = OE.esrgan_hparams(**kw)
+    sd = OE.init_state_dict(hp, seed=4)
+    net = build_network({"type": "esrgan", **kw})
+    net.load_state_dict(sd, strict=True)
+    net = net.to(cuda)
+    net.compute_dtype = dt
+    net.train()
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(1, 3, 360, 376, generator=g)
+    gout = torch.randn(1, 3, 360, 376, generator=g) / (3 * 360 * 376)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ref = OE.forward(params, x, hp, policy)
+    ref_g = OrderedDict(zip(params.keys(), torch.autograd.grad(ref, list(params.values()), gout)))
+    ops.tune_set("ring_launches", 0)
+    out = net.forward_hip(x.to(cuda), train=True)
+    fwd_ring = ops.tune_get("ring_launches")
+    assert fwd_ring == 17, fwd_ring                    # 15 dense convs + trunk conv + HR conv (conv_first: 8 input channels, conv_last: 3 outputs stay on the register kernel)
+    e_fwd = rel_l2(out.cpu(), ref.detach())
+    net.backward_hip(gout.to(cuda))
+    assert ops.tune_get("ring_launches") > fwd_ring + 15
+    errs = {k: rel_l2(p.grad.cpu(), ref_g[k]) for k, p in net.state_dict(keep_vars=True).items()}
+    worst = max(errs, key=errs.get)
+    print(f"{compute_name} RRDB @ ring size: forward rel-L2 {e_fwd:.2e}; worst gradient {worst} {errs[worst]:.2e}; median {sorted(errs.values())[len(errs) // 2]:.2e}")
+    assert e_fwd < 1e-3, e_fwd                         # north_star: bf16 forward activations within 1e-3 relative
+    assert errs[worst] < 1e-2 and sorted(errs.values())[len(errs) // 2] < 2e-3, (worst, errs[worst])

@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SWITCHES = {"TRAINNER_CONV_IMPL": "reg", "TRAINNER_WGRAD_IMPL": "reg", "TRAINNER_WGRAD_MULTI": "0", "TRAINNER_VGG_WINOGRAD": "0",
-            "TRAINNER_NO_POOL_FUSION": "1", "TRAINNER_NO_STEM": "1"}
+SWITCHES = {"TRAINNER_VGG_WINOGRAD": "0", "TRAINNER_NO_POOL_FUSION": "1", "TRAINNER_NO_STEM": "1"}     # host-side selections (perceptual_loss.py)
+TUNE_PLAIN = dict(conv_impl=1, wgrad_impl=1, wgrad_multi=0)                                            # library-side selections (tr_tune_set)
 
 
 def _one_step(monkeypatch, plain: bool):
@@ -44,8 +44,13 @@ def _one_step(monkeypatch, plain: bool):
     g = torch.Generator().manual_seed(7)
     gt = torch.rand(2, 3, 1024, 1024, generator=g).to(dev)
     lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    from trainner_redux_amd import ops
+
     model.feed_data({"lq": lq, "gt": gt})
-    model.optimize_parameters(1, 0, True)
+    ops.tune_set("ring_launches", 0)
+    with ops.tuned(**(TUNE_PLAIN if plain else {})):
+        model.optimize_parameters(1, 0, True)
+    assert (ops.tune_get("ring_launches") == 0) == plain      # the default selection really is the ring kernel at this size
     log = {k: float(v) for k, v in model.get_current_log().items()}
     torch.cuda.synchronize()
     # AdamW's first moment after step 1 is (1 - beta1) * gradient: the gradient itself has been zeroed by the fused optimizer sweep.  (The

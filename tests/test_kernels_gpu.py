@@ -215,7 +215,7 @@ def test_wgrad3x3(cuda, compute_name, shape):
 
 @pytest.mark.parametrize("compute_name", ["bf16", "f16"])
 @pytest.mark.parametrize("geom", [(2, 40, 72), (1, 17, 33)])
-def test_wgrad3x3_multi_dense_block(cuda, compute_name, geom, monkeypatch):
+def test_wgrad3x3_multi_dense_block(cuda, compute_name, geom):
     """tr_wgrad3x3_multi: the five weight / bias gradients of a dense block (spandrel ESRGAN ResidualDenseBlock_5C: conv k reads
     cat(x, x1..x_{k-1}), here channel prefixes of one buffer, and its own slice of the block's gradient buffer) in one launch of the ring
     kernel, against torch's conv2d_weight on the same rounded operands; accumulation on top of existing gradients; and the fallback
@@ -231,15 +231,19 @@ def test_wgrad3x3_multi_dense_block(cuda, compute_name, geom, monkeypatch):
     xd, gyd = nhwc(x).to(cuda, dt), nhwc(gy).to(cuda, dt)
     shapes = [(nf + gc * (c - 1), gc if c < 5 else nf, 0 if c == 5 else nf + gc * (4 - c)) for c in range(1, 6)]
     need = max(ops.wgrad_workspace_bytes(n, h, w, ci, co) for ci, co, _ in shapes)
-    for fused in ("1", "0"):
-        monkeypatch.setenv("TRAINNER_WGRAD_IMPL", "ring")      # these sizes are below the ring kernel's automatic threshold
-        monkeypatch.setenv("TRAINNER_WGRAD_MULTI", fused)
+    for fused in (1, 0):
+        ops.tune_set("wgrad_impl", 2)      # these sizes are below the ring kernel's automatic threshold
+        ops.tune_set("wgrad_multi", fused)
         dws = [torch.full((co, ci, 3, 3), 0.5, device=cuda) for ci, co, _ in shapes]
         dbs = [torch.full((co,), 0.25, device=cuda) for ci, co, _ in shapes]
         wss = [torch.empty(need // 4 + 16, dtype=torch.float32, device=cuda) for _ in shapes]
         convs = [dict(cin=ci, cout=co, inp=ops.view(xd, 0, ci), gy=ops.view(gyd, go, co), dw=dws[k], db=dbs[k], workspace=wss[k])
                  for k, (ci, co, go) in enumerate(shapes)]
-        ops.wgrad3x3_multi(convs, n=n, h=h, w=w, compute=compute, accumulate=True)
+        try:
+            ops.wgrad3x3_multi(convs, n=n, h=h, w=w, compute=compute, accumulate=True)
+        finally:
+            ops.tune_set("wgrad_impl", 0)
+            ops.tune_set("wgrad_multi", 1)
         for k, (ci, co, go) in enumerate(shapes):
             ref_w = torch.nn.grad.conv2d_weight(x[:, :ci], (co, ci, 3, 3), gy[:, go:go + co], padding=1)
             ref_b = gy[:, go:go + co].sum(dim=(0, 2, 3))

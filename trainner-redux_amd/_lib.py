@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 F32_WINOGRAD43 = 101    # ... tr_conv3x3_winograd43_f32 (F(4x4, 3x3), weights from tr_pack_winograd43)
@@ -103,6 +103,8 @@ class AdamWDesc(C.Structure):
 SYMBOLS = {
     "tr_abi_version": (C.c_int, []),
     "tr_last_error": (C.c_char_p, []),
+    "tr_tune_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "tr_tune_get": (C.c_longlong, [C.c_char_p]),
     "tr_conv3x3_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "tr_conv_packed_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_conv3x3": (C.c_int, [C.c_void_p, C.POINTER(Conv3x3Desc)]),

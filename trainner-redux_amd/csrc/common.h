@@ -9,6 +9,22 @@ namespace tr {
 
 void set_error(const char* fmt, ...);
 
+// Kernel-selection switches and the record of the last selection (tr_tune_set / tr_tune_get in trainner_hip.h).  The initial values come
+// from the TRAINNER_* environment variables ONCE, when the library is loaded; launches never call getenv.
+struct Tune {
+    int conv_impl;        // tr_conv3x3, 16-bit 3x3: 0 = automatic, 1 = register-staged kernels only, 2 = the LDS-DMA ring kernel whenever eligible
+    int ring_cfg;         // -1 = automatic; 33 / 32 / 31 = resident-weight pipelined instance with ring depth 3 / 2 / 1; 0 = streamed weights
+    int ring_generic;     // 1 = generic epilogue body instead of the fast forms
+    int wgrad_impl;       // tr_wgrad3x3: 0 = automatic, 1 = register-staged, 2 = ring whenever eligible
+    int wgrad_multi;      // tr_wgrad3x3_multi: 1 = one fused launch per dense block when eligible, 0 = one launch per conv
+    int dgrad_image_ref;  // tr_conv3x3_dgrad_image: 1 = per-pixel reference kernel
+    int last_conv_family; // which kernel family served the calling thread's last tr_conv3x3: 1 reg, 2 dma, 3 linear, 4 ring
+    int last_conv_instance;   // ring: NT*10000 + R*1000 + D*100 + WRES*10 + EPI ; others 0
+    int ring_launches;    // number of tr_conv3x3 launches the ring kernel has served since the counter was last set
+    long long stamps;     // development builds (-DTR_RING_DEV / -DTR_W43_STAMPS) only: device address for in-kernel time stamps
+};
+Tune& tune();
+
 #define TR_REQUIRE(cond, code, ...)                 \
     do {                                            \
         if (!(cond)) {                              \

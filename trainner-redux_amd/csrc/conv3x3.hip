@@ -758,6 +758,7 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
     const int persist = persist_env ? persist_env : ((NT == 1 && R == 2 && (CT == TR_BF16 || CT == TR_F16)) ? 768 : 512);
     const int64_t ntiles = (int64_t)a.ntx * a.nty * a.n * ncg;
     const unsigned grid = (unsigned)(ntiles < persist ? ntiles : persist);
+    tr::tune().last_conv_family = 1;
     hipLaunchKernelGGL((conv3x3_kernel_reg<CT, NT, R, KS>), dim3(grid), dim3(NTHREADS), lds, st, a);
     return tr::launch_status("tr_conv3x3");
 }
@@ -851,6 +852,7 @@ int launch_linear(hipStream_t st, const ConvArgs& a, int nblk) {
     }
     const int total = nblk * a.nty * a.n;
     const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    tr::tune().last_conv_family = 3;
     hipLaunchKernelGGL((linear_kernel<CT, NCG>), dim3(grid), dim3(NTHREADS), lds, st, a, nblk);
     return tr::launch_status("tr_conv3x3(linear)");
 }
@@ -867,6 +869,7 @@ int launch_dma(hipStream_t st, const ConvArgs& a, int ncg) {
         attr_set = true;
     }
     dim3 grid((unsigned)(a.ntx * a.nty * a.n), (unsigned)ncg, 1);
+    tr::tune().last_conv_family = 2;
     hipLaunchKernelGGL((conv3x3_kernel_dma<CT, NT, R>), grid, dim3(NTHREADS), lds, st, a);
     return tr::launch_status("tr_conv3x3");
 }
@@ -930,7 +933,12 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
     hipStream_t st = (hipStream_t)stream;
     static const int dbg = getenv("TRAINNER_CONV_DBG") ? atoi(getenv("TRAINNER_CONV_DBG")) : 0;
     a.dbg = dbg;
-    a.stamps = getenv("TRAINNER_RING_STAMPS") ? (long long*)strtoull(getenv("TRAINNER_RING_STAMPS"), nullptr, 0) : nullptr;
+#ifdef TR_RING_DEV
+    a.stamps = (long long*)tr::tune().stamps;   // development builds only: tr_tune_set("stamps", device address)
+#else
+    a.stamps = nullptr;
+#endif
+    tr::tune().last_conv_instance = 0;
     a.ntx = (a.w + TW - 1) / TW;
     // Staging variant and tile height.  Measured on MI355X (profiles/): the register-staged kernel at two workgroups per
     // CU beats the LDS-DMA kernel at one (each LDS-DMA piece costs the issuing wave 60-100 cycles and the per-CU DMA rate

@@ -472,9 +472,13 @@ __device__ __forceinline__ void ring_epilogue_unit(const ConvArgs& a, f32x16& ac
 }
 
 // diagnostics: wave-uniform time stamp into a[stamps]; slot layout [workgroup][role 0 consumer / 1 loader][256 stamps]
+#ifdef TR_RING_DEV
 #define TR_STAMP(ROLE)                                                                                                  \
     if (a.stamps && l == 0 && (ROLE == 0 ? wv == 0 : wv == NCW) && nst < 256 && blockIdx.x < 1024)                                           \
         a.stamps[((int64_t)blockIdx.x * 2 + ROLE) * 256 + nst++] = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define TR_STAMP(ROLE)
+#endif
 
 template <int CT, int NT, int R, int NCW, int NLW, int WGS, int D, bool WRES, int EPI, bool PIPE>
 __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_ring_kernel(ConvArgs a) {
@@ -863,9 +867,9 @@ bool vec16_ok(const tr_view& v) {   // 16 consecutive channels of a record as 16
 namespace tr {
 
 int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
-    const char* impl = getenv("TRAINNER_CONV_IMPL");   // read per call: tests and A/B tools flip it inside one process          // "reg": never ; "ring": whenever eligible ; unset: eligible and large enough
-    if (impl && !strcmp(impl, "reg")) return -1;
-    const bool force = impl && !strcmp(impl, "ring");
+    const tr::Tune& tn = tr::tune();                  // tr_tune_set("conv_impl", ...): 1 = never ; 2 = whenever eligible ; 0: eligible and large enough
+    if (tn.conv_impl == 1) return -1;
+    const bool force = tn.conv_impl == 2;
     if (d->ksize != 3 || (d->compute != TR_BF16 && d->compute != TR_F16)) return -1;
     if (d->in_mode == TR_IN_VALID || d->in_mode == TR_IN_FULL) return -1;
     if (d->cin % 32 != 0 || d->cout % 8 != 0) return -1;
@@ -884,13 +888,13 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     else fast = d->act == TR_ACT_NONE && d->out.dtype == TR_F32 && (!d->out2.ptr || d->out2.dtype == ct);
     auto img_ok = [&](const tr_view& v) { return !v.ptr || (int64_t)d->h * d->w * v.cstride * tr::esize(v.dtype) < (int64_t)0x7fff0000; };
     if (d->cout % 32 != 0 || !img_ok(d->out) || !img_ok(d->out2) || !img_ok(d->res1) || !img_ok(d->res2) || !img_ok(d->mask)) fast = false;   // buffer addressing of the fast forms
-    if (getenv("TRAINNER_RING_GENERIC")) fast = false;               // A/B switch
+    if (tn.ring_generic) fast = false;                               // A/B switch (and the parity tests of the generic body)
     const int epi = fast ? side : side + 3;
     if (!vec16_ok(d->out) || !vec16_ok(d->out2) || !vec16_ok(d->res1) || !vec16_ok(d->res2) || !vec16_ok(d->mask)) return -1;
     if ((int64_t)a.hin * a.win * d->in.cstride * 2 >= (int64_t)0x7fff0000) return -1;            // buffer addressing: one image below 2 GiB
     const tr::PackGeom g = tr::pack_geom(d->cin, d->cout, d->compute);
     if ((int64_t)g.ncg * g.nchunks * 9 * g.cgw * 64 >= (int64_t)0x7fff0000) return -1;
-    const int cfg_env = getenv("TRAINNER_RING_CFG") ? atoi(getenv("TRAINNER_RING_CFG")) : -1;
+    const int cfg_env = tn.ring_cfg;
     const bool bf = d->compute == TR_BF16;
     const int64_t npix = (int64_t)a.n * a.h * a.w;
     if (!force && npix < 256 * 512) return -1;                       // fewer than ~one 16 x 32 tile per CU: the register-staged kernel's smaller tiles fill the chip better
@@ -899,7 +903,12 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     {                                                                                                                   \
         a.nty = (a.h + (R) * (NCW) - 1) / ((R) * (NCW));                                                                 \
         const int rc = TR_RING_DISPATCH_CT(NT, R, NCW, NLW, WGS, D, WRES, PIPE);                                         \
-        if (rc != -1) return rc;                                                                                        \
+        if (rc != -1) {                                                                                                 \
+            tr::tune().last_conv_family = 4;                                                                            \
+            ++tr::tune().ring_launches;                                                                                 \
+            tr::tune().last_conv_instance = (NT) * 10000 + (R) * 1000 + (D) * 100 + ((WRES) ? 10 : 0) + epi;             \
+            return rc;                                                                                                  \
+        }                                                                                                               \
     }
 #ifdef TR_RING_DEV   /* development builds (TRAINNER_DEV_BUILD=1): bf16 instances only, a third of the compile time */
 #define TR_RING_DISPATCH_CT(NT, R, NCW, NLW, WGS, D, WRES, PIPE) (bf ? launch_ring<TR_BF16, NT, R, NCW, NLW, WGS, D, WRES, PIPE>(st, a, epi) : -1)

@@ -303,7 +303,7 @@ extern "C" int tr_conv3x3_dgrad_image(void* stream, tr_view gy, const float* w_o
         for (int i = 0; i < cin; ++i) t[i] = ch_scale[i];
         chs = make_float4(t[0], t[1], t[2], t[3]);
     }
-    if (cout == 64 && cin == 3 && gy.dtype == TR_F32 && tr::view_vec4_ok(gy) && !getenv("TRAINNER_DGRAD_IMAGE_REF")) {
+    if (cout == 64 && cin == 3 && gy.dtype == TR_F32 && tr::view_vec4_ok(gy) && !tr::tune().dgrad_image_ref) {
         const int ntx = (w + 31) / 32, nty = (h + 7) / 8;
         const int64_t tiles = (int64_t)n * ntx * nty;
         hipLaunchKernelGGL(dgrad_image_tiled_kernel, dim3((unsigned)(tiles < 256 * 24 ? tiles : 256 * 24)), dim3(256), 0, (hipStream_t)stream, gy, w_oihw, n,

@@ -319,9 +319,9 @@ WgRingPlan wgrad_ring_plan(int n, int h, int w, int cin, int cout) {
 
 // -1: not eligible (the caller takes wgrad_kernel); 0: launched (a.nslots etc. describe the partial layout for the reduction); > 0: launch error
 int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPlan& p) {
-    const char* impl = getenv("TRAINNER_WGRAD_IMPL");        // "reg": never ; "ring": whenever eligible ; unset: eligible and large enough
-    if (impl && !strcmp(impl, "reg")) return -1;
-    const bool force = impl && !strcmp(impl, "ring");
+    const int impl = tr::tune().wgrad_impl;                  // tr_tune_set("wgrad_impl", ...): 1 = never ; 2 = whenever eligible ; 0: eligible and large enough
+    if (impl == 1) return -1;
+    const bool force = impl == 2;
     if (d->ksize != 3 || (d->compute != TR_BF16 && d->compute != TR_F16)) return -1;
     if (d->in_mode == TR_IN_VALID || d->in_mode == TR_IN_FULL) return -1;
     if (d->cin % 8 != 0 || d->cout % 8 != 0) return -1;
@@ -372,13 +372,12 @@ int wgrad3x3_ring(hipStream_t st, const tr_wgrad3x3_desc* d, WgArgs& a, WgRingPl
 }
 
 int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc, int* nslots_out) {
-    const char* impl = getenv("TRAINNER_WGRAD_IMPL");
-    if (impl && !strcmp(impl, "reg")) return -1;
-    if (getenv("TRAINNER_WGRAD_MULTI") && !strcmp(getenv("TRAINNER_WGRAD_MULTI"), "0")) return -1;
+    const int impl = tr::tune().wgrad_impl;
+    if (impl == 1 || !tr::tune().wgrad_multi) return -1;
     const tr_wgrad3x3_desc& d0 = descs[0];
     if (d0.ksize != 3 || (d0.compute != TR_BF16 && d0.compute != TR_F16) || d0.in_mode != TR_IN_DIRECT) return -1;
     if ((int64_t)d0.h * d0.w * d0.in.cstride * 2 >= (int64_t)0x7fff0000 || (int64_t)d0.h * d0.w * d0.gy.cstride * 2 >= (int64_t)0x7fff0000) return -1;
-    if ((int64_t)d0.n * d0.h * d0.w < 256 * 512 && !(impl && !strcmp(impl, "ring"))) return -1;
+    if ((int64_t)d0.n * d0.h * d0.w < 256 * 512 && impl != 2) return -1;
     // 32-wide output units (conv, 64-channel input block, group), paired up per input block into 64-wide roles: an x tile staged in LDS serves two
     struct Unit { int k, pc, cg; };
     Unit units[3][2 * TR_WG_MAX_ROLES];

@@ -589,7 +589,11 @@ extern "C" int tr_conv3x3_winograd43_f32(void* stream, const tr_conv3x3_desc* d)
     a.u = (const float*)d->wpacked; a.bias = d->bias;
     a.nty = (d->h + 15) / 16; a.ntx = (d->w + 31) / 32;
     a.nchunks = d->cin / Q_CK; a.nkg = d->cout / Q_KB;
-    a.stamps = getenv("TRAINNER_W43_STAMPS") ? (long long*)strtoull(getenv("TRAINNER_W43_STAMPS"), nullptr, 0) : nullptr;
+#ifdef TR_W43_STAMPS
+    a.stamps = (long long*)tr::tune().stamps;   // development builds only: tr_tune_set("stamps", device address)
+#else
+    a.stamps = nullptr;
+#endif
     const int64_t nblk = (int64_t)d->n * a.nty * a.ntx * a.nkg;
     TR_REQUIRE(nblk < (int64_t)0x7fffffff, TR_EUNSUPPORTED, "tr_conv3x3_winograd43_f32: grid too large");
     static const hipError_t attr = [] {

@@ -57,6 +57,44 @@ def view(t: torch.Tensor | None, coff: int = 0, c: int | None = None) -> L.View:
 NULL_VIEW = L.View(None, 0, 0, 0, 0)
 
 
+def tune_set(key: str, value: int) -> None:
+    """tr_tune_set: process-wide kernel-selection switch (include/trainner_hip.h lists the keys)."""
+    L.check(L.lib().tr_tune_set(key.encode(), int(value)), f"tr_tune_set({key})")
+
+
+def tune_get(key: str) -> int:
+    v = int(L.lib().tr_tune_get(key.encode()))
+    if v == -1 and key not in ("ring_cfg",):
+        L.check(-1, f"tr_tune_get({key})")
+    return v
+
+
+class tuned:
+    """`with ops.tuned(conv_impl=2, ring_cfg=32): ...` -- set switches for a block, restore the previous values after it."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = int(L.lib().tr_tune_get(k.encode()))
+            tune_set(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            tune_set(k, v)
+        return False
+
+
+CONV_FAMILIES = {0: "none", 1: "reg", 2: "dma", 3: "linear", 4: "ring"}
+
+
+def last_conv_family() -> str:
+    """Which kernel family served the last tr_conv3x3 launch of this process."""
+    return CONV_FAMILIES[tune_get("last_conv_family")]
+
+
 def packed_bytes(cin: int, cout: int, compute: int, ksize: int = 3) -> int:
     return int(L.lib().tr_conv_packed_bytes(cin, cout, compute, ksize))
 
