@@ -4,8 +4,9 @@
   tensor2img rounding                     /root/reference/traiNNer/utils/img_util.py (clamp, x255, round, uint8)
   to_y_channel / rgb2ycbcr(y_only)        /root/reference/traiNNer/metrics/metric_util.py:34-47, utils/color_util.py
   infer_tiled                             /root/reference/traiNNer/models/sr_model.py:830-900
-Parity unpinned: the reference versions call cv2 (absent here); the Gaussian window is cv2.getGaussianKernel's closed form and
-`filter2D(...)[5:-5, 5:-5]` is a valid-region correlation, restated with float64 conv2d.
+Pinned: `psnr` (the numpy calculate_psnr incl. to_y_channel) and `psnr_pt` against the reference functions' own outputs (tests/golden/psnr.pt,
+made by tests/golden/make_golden_twins.py; tests/test_twins_cpu.py).  Parity unpinned: SSIM -- the reference versions call cv2 (absent here); the
+Gaussian window is cv2.getGaussianKernel's closed form and `filter2D(...)[5:-5, 5:-5]` is a valid-region correlation, restated with float64 conv2d.
 """
 from __future__ import annotations
 
@@ -34,6 +35,20 @@ def psnr(img, img2, crop_border, test_y_channel=False):
     a, b = _prep(img, crop_border, test_y_channel), _prep(img2, crop_border, test_y_channel)
     mse = ((a - b) ** 2).mean().item()
     return float("inf") if mse == 0 else 10.0 * math.log10(255.0 * 255.0 / mse)
+
+
+def psnr_pt(img, img2, crop_border, test_y_channel=False):
+    """calculate_psnr_pt (/root/reference/traiNNer/metrics/psnr_ssim.py:64-98): (n, 3/1, h, w) in [0, 1], no 8-bit rounding, one value per image;
+    Y = rgb2ycbcr_pt(y_only) (utils/color_util.py: (65.481 R + 128.553 G + 24.966 B + 16) / 255).  Pinned: tests/golden/psnr.pt."""
+    if crop_border:
+        img = img[:, :, crop_border:-crop_border, crop_border:-crop_border]
+        img2 = img2[:, :, crop_border:-crop_border, crop_border:-crop_border]
+    if test_y_channel:
+        wgt = torch.tensor([[65.481], [128.553], [24.966]]).to(img)
+        img = (torch.matmul(img.permute(0, 2, 3, 1), wgt).permute(0, 3, 1, 2) + 16.0) / 255.0
+        img2 = (torch.matmul(img2.permute(0, 2, 3, 1), wgt).permute(0, 3, 1, 2) + 16.0) / 255.0
+    mse = ((img.double() - img2.double()) ** 2).mean(dim=[1, 2, 3])
+    return 10.0 * torch.log10(1.0 / (mse + 1e-8))
 
 
 def ssim(img, img2, crop_border, test_y_channel=False):

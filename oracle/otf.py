@@ -7,9 +7,12 @@ Follows, function by function,
   oversharpening, aliasing                             /root/reference/traiNNer/models/realesrgan_model.py:193-241,365-402
   demosaicing artifacts                                /root/reference/traiNNer/models/realesrgan_model.py:312-363 (cv2.demosaicing restated: unpinned)
   the stage order and RNG draws of feed_data           /root/reference/traiNNer/models/realesrgan_model.py:456-664
-The reference modules themselves do not import here (cv2 / torchvision / msgspec are absent), and RealESRGANModel has no CPU path at all
-(hard-coded .cuda()): resizes are pinned on torch's own F.interpolate, which is what the reference calls; the
-stochastic pipeline as a whole is "parity unpinned" beyond that.
+Pinned (round 3): models/paragon_otf_degradations.py DOES load by path here (numpy / torch / PIL + a two-line RNG stand-in), so every codec-free
+static stage -- motion blur, lens distortion, exposure, colour temperature, sensor noise, rolling shutter, oversharpening, chromatic aberration,
+aliasing -- is checked against the reference function's own seeded outputs (tests/golden/paragon_otf.pt, tests/test_twins_cpu.py); resizes and
+filter2d against theirs (otf_degradations.pt, filter2d.pt).  Still unpinned: the demosaicing stage (cv2.demosaicing is absent) and the codec
+round trips (PIL encoders; statistical only, as in the reference).  RealESRGANModel.feed_data itself has no CPU path (hard-coded .cuda(), SURVEY.md
+section 9): the stage ORDER is restated from realesrgan_model.py:456-664.
 """
 from __future__ import annotations
 

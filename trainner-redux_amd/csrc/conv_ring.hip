@@ -1,8 +1,10 @@
 // 3x3 / stride 1 / pad 1 convolution on NHWC channel-slice views, 16-bit operands: persistent LDS-DMA ring kernel.
 //
 // Contract: include/trainner_hip.h (tr_conv3x3); this is the kernel the RRDB trunk and the upsampling tail of ESRGAN run on
-// (reference arithmetic: traiNNer/archs/scunet_aaf6aa_arch.py:310-384, see conv3x3.hip).  Same packed weight slabs, same MFMA
-// orientation D[cout][pixel] and the same accumulation order as conv3x3_kernel_reg, so the two kernels agree bit for bit.
+// (reference arithmetic: traiNNer/archs/scunet_aaf6aa_arch.py:310-384, see conv3x3.hip).  Same packed weight slabs and the same MFMA
+// orientation D[cout][pixel] as conv3x3_kernel_reg; the bias seeds the accumulators here and is added in the epilogue there, so the two
+// kernels differ in the last fp32 place (measured 2.4e-7 rel-L2 on fp32 outputs, 99.9 % of 16-bit outputs identical): each is held to
+// F.conv2d separately (tests/test_conv_ring_gpu.py, tests/test_kernels_gpu.py).
 //
 // Why a second kernel ("ring kernel"): the register-staged kernel moves every operand global -> VGPR -> LDS
 // with two workgroup barriers per 32-channel chunk and transposes its accumulators through LDS before storing; on the RRDB shapes
@@ -631,9 +633,12 @@ __global__ __launch_bounds__((NCW + NLW) * 64, WGS * (NCW + NLW) / 4) void conv_
 
     // ===================================================== consumer waves =====================================================
     // the bias seeds the accumulators (no add in the epilogue): all output groups, zero padded, in LDS behind the ring
+    // EVERY consumer wave writes the whole array (identical values: the duplicates are benign) and waits for its own writes: a pipelined instance
+    // with ring depth 1 seeds its first accumulators before any barrier, so a wave may not rely on another wave's writes here (round 3: with one
+    // wave writing, waves 1..3 of the D = 1 instances read stale LDS -- found by tests/test_conv_ring_gpu.py with ring_cfg = 31)
     float* bias_lds = (float*)(ring + C::S * C::STAGE_BYTES);
-    for (int i = tid; i < a.ncg * C::CGW; i += NCW * 64) bias_lds[i] = (a.bias && i < a.cout) ? a.bias[i] : 0.f;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // visible to the other consumer waves behind the first barrier
+    for (int i = l; i < a.ncg * C::CGW; i += 64) bias_lds[i] = (a.bias && i < a.cout) ? a.bias[i] : 0.f;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const FragAddr fa = make_frag_addr(lr, lh);
     if constexpr (PIPE) {
         // ---- pipelined consumers (fast epilogue forms with SIDE 0 / 1 only): two accumulator sets; tile k's epilogue runs as U + 1 stages hooked
@@ -924,7 +929,7 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
         const int cfg = cfg_env >= 0 ? cfg_env : (d->cin <= 128 ? 33 : 0);
         if (g.ncg == 1 && cfg >= 30) {
             if (cfg == 33) TR_RING_LAUNCH(1, 2, 4, 4, 1, 3, true, true)
-            TR_RING_LAUNCH(1, 2, 4, 4, 1, 2, true, true)
+            if (cfg >= 32) TR_RING_LAUNCH(1, 2, 4, 4, 1, 2, true, true)
             TR_RING_LAUNCH(1, 2, 4, 4, 1, 1, true, true)
         }
         TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false, false)
