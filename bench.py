@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: training images/sec of `SRModel.optimize_parameters` on synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU; under torch.distributed.run the ranks are given, with
+                                                            WORLD_SIZE unset bench.py starts the N rank processes itself and relays rank 0's line)
 
 Workload at N = 1 (BASELINE.json configs[1]): ESRGAN 4x (RRDBNet 23 blocks), L1 + perceptual (VGG19, `perceptualloss`
 = fp32), bf16 compute, 256x256 -> 1024x1024 tiles, batch 16 per GPU, AdamW + EMA, every step applies the gradient.
@@ -9,8 +10,10 @@ A "step" = one full `optimize_parameters` call on one resident batch; value = gl
 Weak scaling: per-GPU batch is fixed; gradients are exchanged with ONE RCCL all-reduce of the flat gradient arena.
 
 The JSON line also carries
-  roofline     -- dominant kernel (the fp32 VGG convs, run as fused Winograd MFMA kernels): algorithmic FLOPs per launch / its average launch
-                  duration, measured live with HIP events on the launch stream during the timed region;
+  roofline     -- dominant kernel group by time (configs[1]: the fp32 VGG convs, run as fused Winograd F(4x4,3x3) MFMA kernels): FLOPs the kernel
+                  EXECUTES on the MFMA pipe per launch / its average launch duration, measured live with HIP events on the launch stream during
+                  the timed region (`frac` <= 1 against the dense MFMA peak of the dtype); the algorithmic 3x3-convolution rate is reported next
+                  to it (`algorithmic_tflops`, `algorithmic_vs_direct_peak`), as are algorithmic bytes, counter-measured HBM bytes and `hbm_frac`;
   cpu_baseline -- the oracle's step (pure PyTorch fp32, the reference's CPU path) timed on this host on a bounded
                   sample and scaled to the same unit.
 """
@@ -49,6 +52,10 @@ def parse():
     ap.add_argument("--fast-matmul", action="store_true", help="the reference's fast_matmul option: split-bf16 (3 bf16 MFMAs per product) for the fp32-forced VGG; NOT the default line")
     ap.add_argument("--graphs", action="store_true", help="use_compile: true -> the generator's forward / backward replay as hipGraphs (helps the host-launch-bound "
                                                           "small-tile configs; the per-launch roofline timers then see only the launches outside the graphs)")
+    ap.add_argument("--loader", action="store_true", help="also time the same steps fed by the real loader (PNG files -> PairedImageDataset(as_uint8) -> pinned "
+                                                          "DevicePrefetcher, side-stream H2D + on-device uint8 -> fp32 NCHW): reported as variants.real_loader, never as `value`")
+    ap.add_argument("--no-loader", action="store_true", help="skip the real-loader leg (it runs by default for the esrgan workloads on one GPU)")
+    ap.add_argument("--loader-workers", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational fast_matmul measurement")
     ap.add_argument("--no-roofline", action="store_true")
@@ -58,6 +65,7 @@ def parse():
     args.scale = args.scale or (2 if span else 4)
     args.batch = args.batch or (64 if span else 8 if swin else 16)
     args.lq = args.lq or (64 if swin else 256)
+    args.loader = (args.loader or args.arch == "esrgan") and not args.no_loader and not args.otf
     if swin and args.losses != "l1":
         args.losses = "l1"            # configs[3] names no perceptual head; the reference's SwinIR template trains on a pixel loss
     return args
@@ -113,20 +121,31 @@ class ConvTimer:
             e1.record()
             cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32w4" if kw["compute"] == L.F32_WINOGRAD43 else "f32"
             ks = kw.get("ksize", 3)
-            flops = 2.0 * kw["n"] * kw["h"] * kw["w"] * ks * ks * kw["cin"] * kw["cout"]
-            timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1))
+            npix = float(kw["n"]) * kw["h"] * kw["w"]
+            flops = 2.0 * npix * ks * ks * kw["cin"] * kw["cout"]
+            # algorithmic bytes of the launch: input read once (a quarter of the pixels under nearest-2x), every output / side view once
+            es = lambda v: 4 if v.dtype == L.F32 else 2  # noqa: E731
+            nbytes = npix * kw["cin"] * es(kw["inp"]) * (0.25 if kw.get("in_mode") == L.IN_NEAREST2X else 1.0)
+            for name in ("out", "out2", "res1", "res2", "mask"):
+                v = kw.get(name)
+                if v is not None and v.ptr:
+                    nbytes += npix * kw["cout"] * es(v) * (0.25 if (name == "out2" and cd == "f32w4") else 1.0)      # Winograd's second output is the 2x2-pooled map
+            fam = "winograd" if cd in ("f32w", "f32w4") else ops.last_conv_family()
+            timer.records.append(((cd, 64 if kw["cout"] > 32 else 32, ks), flops, e0, e1, nbytes, fam))
 
         ops.conv3x3 = timed
         # archs call `ops.conv3x3(...)` through the module attribute, so the wrapper is seen everywhere
 
     def summary(self):
         agg = {}
-        for key, flops, e0, e1 in self.records:
+        for key, flops, e0, e1, nbytes, fam in self.records:
             ms = e0.elapsed_time(e1)
-            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, {}])
             a[0] += 1
             a[1] += flops
             a[2] += ms
+            a[3] += nbytes
+            a[4][fam] = a[4].get(fam, 0) + 1
         return agg
 
 
@@ -196,14 +215,198 @@ def cpu_baseline(args, perceptual: bool):
             break
     dt = (time.perf_counter() - t0) / reps
     scale = (args.lq / s_lq) ** 2
-    return dict(value=1.0 / (dt * scale), unit="images/sec", cores=threads, kind="port",
-                sample=f"{reps} oracle steps of batch 1 at {s_lq}->{args.scale * s_lq} ({dt:.2f} s each, fp32, {threads} threads); "
-                       f"one {args.lq}->{args.scale * args.lq} image = {scale:.0f}x those pixels, value scaled by 1/{scale:.0f}")
+    res = dict(value=1.0 / (dt * scale), unit="images/sec", cores=threads, kind="port",
+               sample=f"{reps} oracle steps of batch 1 at {s_lq}->{args.scale * s_lq} ({dt:.2f} s each, fp32, {threads} threads); "
+                      f"one {args.lq}->{args.scale * args.lq} image = {scale:.0f}x those pixels, value scaled by 1/{scale:.0f}")
+    if args.arch == "esrgan":
+        res["cfg1"] = cpu_baseline_cfg1(args.blocks, threads)
+    return res
+
+
+def cpu_baseline_cfg1(blocks: int, threads: int):
+    """BASELINE.json configs[0] exactly (SURVEY.md section 8d "CPU baseline beside it"): ESRGAN 4x, L1 only, batch 2, 64 -> 256, fp32, AdamW + EMA -- the
+    oracle's step on all host threads, and batch 1 on ONE thread for a per-core figure.  Bounded: one warm-up + timed steps for ~6 s each."""
+    from collections import OrderedDict
+
+    from oracle import esrgan as OE, losses as OL, step as OS
+
+    hp = OE.esrgan_hparams(scale=4, num_blocks=blocks)
+    sd = OE.init_state_dict(hp, 0)
+    out = {}
+    for tag, nthr, nb in (("all_threads", threads, 2), ("one_thread", 1, 1)):
+        torch.set_num_threads(nthr)
+        params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+        st = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+        ema = OS.EMAState(OrderedDict((k, v.data) for k, v in params.items()), beta=0.999, power=0.75)
+        g = torch.Generator().manual_seed(1024)
+        gt = torch.rand(nb, 3, 256, 256, generator=g)
+        lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+        fns = OrderedDict(l_g_l1=(OL.l1, 1.0))
+        fwd = lambda p, x: OE.forward(p, x, hp)  # noqa: E731
+        if nthr > 1:
+            OS.generator_step(params, fwd, fns, lq, gt, st, ema)      # warm-up (the one-thread leg is too slow to repeat: its single step is the sample)
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 1 or (nthr > 1 and time.perf_counter() - t0 < 6.0):
+            OS.generator_step(params, fwd, fns, lq, gt, st, ema)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        out[tag] = dict(value=nb / dt, unit="images/sec (64->256 tiles)", cores=nthr, batch=nb, s_per_step=dt, steps=reps,
+                        tflops=nb * 0.4406 / dt)                     # 0.4406 TFLOP per trained 64 -> 256 image (SURVEY.md section 8d)
+    torch.set_num_threads(threads)
+    return out
+
+
+def real_loader_leg(args, model, n, s, sc, it):
+    """The same training steps fed by the real loader ("data already resident (synthetic) and, separately, with the real loader"):
+    synthetic PNG pairs on local disk -> PairedImageDataset(as_uint8) (PIL decode, paired flip / rot / crop on uint8) -> DataLoader workers -> pinned
+    DevicePrefetcher (side-stream H2D of uint8 HWC, tr_u8hwc_to_nchw on the device) -> feed_data -> optimize_parameters."""
+    import tempfile
+
+    import numpy as np
+    from PIL import Image
+
+    from trainner_redux_amd.data.paired_image_dataset import PairedImageDataset
+    from trainner_redux_amd.data.prefetch import DevicePrefetcher, build_dataloader
+
+    workers = args.loader_workers if args.loader_workers is not None else max(2, min(12, host_threads() - 2))
+    steps = args.steps
+    with tempfile.TemporaryDirectory(prefix="tr_bench_") as root:
+        rng = np.random.default_rng(7)
+        npairs = max(2 * n, 32)
+        gsz = sc * s + 2 * sc * 8                       # a little larger than the crop, so that the random crop really moves
+        os.makedirs(os.path.join(root, "gt")); os.makedirs(os.path.join(root, "lq"))
+        for i in range(npairs):
+            gt = rng.integers(0, 256, (gsz, gsz, 3), dtype=np.uint8)
+            Image.fromarray(gt).save(os.path.join(root, "gt", f"{i:04d}.png"), compress_level=1)
+            Image.fromarray(gt[::sc, ::sc]).save(os.path.join(root, "lq", f"{i:04d}.png"), compress_level=1)
+        ds = PairedImageDataset(dict(name="bench", phase="train", scale=sc, dataroot_gt=[os.path.join(root, "gt")], dataroot_lq=[os.path.join(root, "lq")],
+                                     gt_size=sc * s, use_hflip=True, use_rot=True), as_uint8=True)
+
+        class Repeat(torch.utils.data.Dataset):        # enough items for warm-up + timed steps (dataset_enlarge_ratio of the reference's sampler)
+            def __len__(self):
+                return n * (steps + 3)
+
+            def __getitem__(self, i):
+                return ds[i % len(ds)]
+
+        loader = build_dataloader(Repeat(), n, num_workers=workers, seed=1024)
+        pre = DevicePrefetcher(loader, model.device)
+        for _ in range(2):                              # warm-up: worker start-up, first decode
+            it += 1
+            model.feed_data(pre.next())
+            model.optimize_parameters(it, 0, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it += 1
+            model.feed_data(pre.next())
+            model.optimize_parameters(it, 0, True)
+            model.update_learning_rate(it, -1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        del pre, loader
+    return {"value": n * steps / dt, "unit": "images/sec", "ms_per_step": dt / steps * 1e3, "workers": workers,
+            "what": f"same workload, every batch decoded from {sc * s + 16 * sc}^2 / {s + 16}^2 PNG pairs by PairedImageDataset(as_uint8) in {workers} loader workers, "
+                    "shipped as pinned uint8 HWC by DevicePrefetcher and converted on the device; not the headline value"}
+
+
+PEAK_TFLOPS = {"f32": 157.3, "f32w": 157.3, "f32w4": 157.3, "bf16": 2500.0, "f16": 2500.0}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0
+WINO_FACTOR = {"f32w": 2.25, "f32w4": 4.0}          # algorithmic multiplies per multiply the Winograd forms execute on the MFMA pipe
+
+
+def workload_key(args, n, s):
+    return f"{args.arch}/{args.losses}/{args.compute}/batch{n}/lq{s}" + (f"/blocks{args.blocks}" if args.arch == "esrgan" else "") + ("/gan" if args.gan else "")
+
+
+def roofline(args, agg, dt, n, s):
+    """The dominant kernel group (by summed launch time inside the timed region) against the roofline that bounds it.
+
+    executed FLOPs = algorithmic 3x3-convolution FLOPs / WINO_FACTOR (1 for the direct kernels); arithmetic intensity = executed FLOPs /
+    algorithmic bytes; bound = mfma when that intensity lies above the ridge (peak FLOP/s / 8 TB/s), else hbm.  `achieved` / `frac` are the
+    executed MFMA rate (mfma) or the algorithmic byte rate (hbm) against that roof -- never above 1.  `traffic` = HBM bytes per launch from the
+    committed PMC passes (profiles/traffic.json, only for the workload they were taken on); `hbm_frac` = traffic / launch time / 8 TB/s."""
+    traffic_tab = {}
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        traffic_tab = tj.get("workloads", {}).get(workload_key(args, n, s), {})
+    except Exception:
+        pass
+
+    def entry(k, v):
+        cnt, flops, msum, nbytes, fams = v
+        wf = WINO_FACTOR.get(k[0], 1.0)
+        peak = PEAK_TFLOPS[k[0]]
+        alg = flops / (msum * 1e-3) / 1e12
+        exe = alg / wf
+        gbps = nbytes / (msum * 1e-3) / 1e9
+        ridge = peak * 1e12 / (PEAK_HBM_GBPS * 1e9)
+        ai = (flops / wf) / max(nbytes, 1.0)
+        tkey = {"f32w": "f32/winograd", "f32w4": "f32/winograd43"}.get(k[0], f"{k[0]}/cg{k[1]}") + ("" if k[2] == 3 else f"/k{k[2]}")
+        tr = traffic_tab.get(tkey, {}).get("traffic_bytes_per_launch")
+        e = {"launches": cnt, "ms": msum, "avg_launch_ms": msum / cnt, "kernel_family": fams,
+             "algorithmic_tflops": alg, "executed_mfma_tflops": exe, "mfma_frac": exe / peak,
+             "algorithmic_bytes_per_launch": nbytes / cnt, "algorithmic_gbps": gbps, "algorithmic_hbm_frac": gbps / PEAK_HBM_GBPS,
+             "intensity_flop_per_byte": ai, "ridge_flop_per_byte": ridge, "bound": "mfma" if ai >= ridge else "hbm"}
+        if tr is not None:
+            e["traffic"] = tr
+            e["hbm_frac"] = tr / (msum / cnt * 1e-3) / (PEAK_HBM_GBPS * 1e9)
+            e["traffic_over_algorithmic"] = tr / (nbytes / cnt)
+        return tkey, e
+
+    table = dict(entry(k, v) for k, v in agg.items())
+    key = max(agg, key=lambda k: agg[k][2])
+    tkey, e = entry(key, agg[key])
+    names = {"f32w": "winograd_f32_kernel (fused Winograd F(2x2,3x3), fp32 MFMA)", "f32w4": "winograd43_f32_kernel (fused Winograd F(4x4,3x3), fp32 MFMA)"}
+    fam = max(e["kernel_family"], key=e["kernel_family"].get)
+    fam_name = {"ring": "conv_ring_kernel (persistent LDS-DMA ring)", "reg": "conv3x3_kernel_reg (register-staged)", "linear": "linear_kernel (token GEMM)",
+                "dma": "conv3x3_kernel_dma"}.get(fam, fam)
+    kname = names.get(key[0], f"{fam_name} <{key[0]}, cout-group {key[1]}, ksize {key[2]}>")
+    mfma = e["bound"] == "mfma"
+    r = {"bound": e["bound"], "kernel": kname,
+         "achieved": e["executed_mfma_tflops"] if mfma else e["algorithmic_gbps"], "peak": PEAK_TFLOPS[key[0]] if mfma else PEAK_HBM_GBPS,
+         "unit": "TFLOP/s" if mfma else "GB/s", "frac": e["mfma_frac"] if mfma else e["algorithmic_hbm_frac"],
+         "traffic": e.get("traffic"), "hbm_frac": e.get("hbm_frac"), "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
+         "traffic_over_algorithmic": e.get("traffic_over_algorithmic"),
+         "flop_per_launch": agg[key][1] / agg[key][0], "launches": agg[key][0], "avg_launch_ms": e["avg_launch_ms"], "share_of_step": agg[key][2] / (dt * 1e3),
+         "algorithmic_tflops": e["algorithmic_tflops"], "algorithmic_vs_direct_peak": e["algorithmic_tflops"] / PEAK_TFLOPS[key[0]],
+         "note": ("achieved / frac = FLOPs the kernel EXECUTES on the MFMA pipe (algorithmic 3x3-conv FLOPs / "
+                  f"{WINO_FACTOR.get(key[0], 1.0):g}) over the launch time, against the dense {key[0][:3]} MFMA peak; algorithmic_* = the 2*9*Cin*Cout-per-pixel "
+                  "rate of the convolution itself (DESIGN.md section 4)") if mfma else
+                 "achieved / frac = algorithmic bytes (input once + every output / side view once) over the launch time, against 8 TB/s",
+         "all": table}
+    return r
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL) as children through torch.distributed.run --
+    decided before this process touches the GPU -- and relay their output; rank 0 prints the JSON line.  The ranks see the same argv."""
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if ndev < n:
+        print(json.dumps({"error": f"--gpus {n} asked for, {ndev} visible"}))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"starting {n} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"note: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus reports the ranks RCCL sees")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -213,6 +416,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
+        world = dist.get_world_size()
     dev = torch.device("cuda", local_rank)
 
     import trainner_redux_amd  # noqa: F401
@@ -298,30 +502,7 @@ def main():
                        "l_g_total": stats.get("l_g_total")},
         }
         if not args.no_roofline and timer.records:
-            agg = timer.summary()
-            key = max(agg, key=lambda k: agg[k][2])
-            cnt, flops, msum = agg[key]
-            peak = 157.3 if key[0] in ("f32", "f32w", "f32w4") else 2500.0
-            wino_factor = {"f32w": 2.25, "f32w4": 4.0}.get(key[0])     # algorithmic multiplies per executed multiply of the Winograd forms
-            ach = flops / (msum * 1e-3) / 1e12
-            traffic = None   # HBM bytes per launch from the committed PMC passes, valid only for the workload they were taken on
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if args.arch == "esrgan" and tj.get("workload") == f"{args.losses}/{args.compute}/batch{n}/lq{s}/blocks{args.blocks}":
-                    traffic = tj[{"f32w": "f32/winograd", "f32w4": "f32/winograd43"}.get(key[0], f"{key[0]}/cg{key[1]}")]["traffic_bytes_per_launch"] if key[2] == 3 else None
-            except Exception:
-                traffic = None
-            kname = {"f32w": "winograd_f32_kernel (fused Winograd F(2x2,3x3), fp32 MFMA)",
-                     "f32w4": "winograd43_f32_kernel (fused Winograd F(4x4,3x3), fp32 MFMA)"}.get(key[0], f"conv3x3 kernels <{key[0]}, cout-group {key[1]}, ksize {key[2]}>")
-            out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "flop_per_launch": flops / cnt, "launches": cnt,
-                               "avg_launch_ms": msum / cnt,
-                               "share_of_step": msum / (dt * 1e3),
-                               **({"mfma_executed_tflops": ach / wino_factor, "mfma_executed_frac": ach / wino_factor / peak,
-                                   "note": "achieved / frac count the ALGORITHMIC FLOPs of the 3x3 convolution (2*9*Cin*Cout per pixel, DESIGN.md section 4); the "
-                                           f"Winograd kernel executes 1/{wino_factor:g} of those multiplies on the MFMA units (mfma_executed_*), which is how a frac above "
-                                           "the direct-convolution roofline is reached in fp32 arithmetic"} if wino_factor else {}),
-                               "all": {f"{k[0]}/cg{k[1]}" + ("" if k[2] == 3 else f"/k{k[2]}"): {"launches": v[0], "tflops": v[1] / (v[2] * 1e-3) / 1e12, "ms": v[2]} for k, v in agg.items()}}
+            out["roofline"] = roofline(args, timer.summary(), dt, n, s)
         if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
             # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the
             # split-bf16 path of the fp32-forced VGG head (3 bf16 MFMAs per product; measured 3e-6 rel-L2 per conv vs exact fp32)
@@ -341,6 +522,8 @@ def main():
                 out["variants"] = {"fast_matmul": {"value": n * args.steps / dt2, "unit": "images/sec", "ms_per_step": dt2 / args.steps * 1e3,
                                                    "what": "same workload with the reference option fast_matmul: true (split-bf16 MFMAs in the fp32-forced "
                                                            "VGG head; everything else unchanged); not the headline value"}}
+        if args.loader and world == 1:
+            out.setdefault("variants", {})["real_loader"] = real_loader_leg(args, model, n, s, sc, it)
         if not args.no_cpu_baseline and world == 1:
             log(f"cpu baseline on {host_threads()} threads")
             out["cpu_baseline"] = cpu_baseline(args, "perceptual" in args.losses)

@@ -44,6 +44,26 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     # every parameter's .grad is a view of the arena, so p.grad already holds the averaged gradient
     p0 = next(net.parameters())
     assert torch.equal(p0.grad.reshape(-1), grads[: p0.numel()])
+    # GradExchange: buckets cut from the END of the arena, each launched as soon as backward reports its range final, 1/world applied at the end
+    from trainner_redux_amd.utils.dist_util import GradExchange
+
+    grads.copy_(mine)
+    ex = GradExchange(grads, bucket_bytes=1 << 20)
+    assert ex.buckets[0][1] == grads.numel() and ex.buckets[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(ex.buckets, ex.buckets[1:]))
+    net.grad_exchange = ex
+    ex.begin()
+    plist = [p for p in net.parameters()]
+    order = [plist[-1], plist[len(plist) // 2], plist[len(plist) // 2], plist[1]]      # backward finishes parameters from the last towards the first
+    launched = []
+    for p in order:
+        net._grads_final_from(p)
+        launched.append(ex.next)
+    assert launched[0] <= launched[1] == launched[2] <= launched[3] < len(ex.buckets)   # monotone, idempotent, the first bucket waits for finish()
+    assert all(ex.buckets[i][0] >= off for i, off in ex.launch_log)                    # no bucket went out before its whole range was final
+    ex.finish()
+    assert ex.next == len(ex.buckets) and not ex.active
+    assert torch.allclose(grads, sum(others) / world, atol=1e-6)
+    net.grad_exchange = None
     s = EnlargedSampler(list(range(11)), world, rank, ratio=2)
     s.set_epoch(3)
     idx = torch.tensor(list(iter(s)))

@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist", "_frozen_arena")
+_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist", "_frozen_arena", "_offset_of", "grad_exchange")
 
 
 class FlatParamModule(nn.Module):
@@ -20,6 +20,20 @@ class FlatParamModule(nn.Module):
     # training steps replay forward_hip / backward_hip as two hipGraphs instead of enqueueing ~700 launches each from Python
     hip_graphs = False
     GRAPH_WARMUP = 2          # eager steps before capture: they size the buffer pools and the per-stream scratch
+
+    grad_exchange = None      # utils.dist_util.GradExchange of the gradient arena (set by the trainer when world_size > 1): backward_hip reports
+                              # finished parameter ranges to it through `_grads_final_from`, the exchange then overlaps the rest of backward
+
+    def _grads_final_from(self, param) -> None:
+        """All gradients of `param` and of every parameter registered after it are final (their last accumulating launch is enqueued)."""
+        ex = self.grad_exchange
+        if ex is None or not ex.active or (ex.flat.is_cuda and torch.cuda.is_current_stream_capturing()):     # (a hipGraph capture records kernels only: the exchange
+            return                                                                       #  then runs as a whole after the replay, GradExchange.finish)
+        offs = self.__dict__.get("_offset_of")
+        if offs is None or offs.get("_arena_ptr") != self._grad_arena.data_ptr():
+            offs = self._offset_of = {id(p): o for p, o in zip(self._plist, self._offsets)}
+            offs["_arena_ptr"] = self._grad_arena.data_ptr()
+        ex.ready_from(offs[id(param)])
 
     def _init_arena_state(self) -> None:
         self._gs = None

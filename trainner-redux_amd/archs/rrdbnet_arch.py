@@ -319,11 +319,13 @@ class RRDBNet(FlatParamModule):
         ops.nchw_to_nhwc(grad_out, ws.g8)
         cl = getattr(m, str(self._idx_last))
         wgrad(cl, V(ws.UH), V(ws.g8), H, W)
+        self._grads_final_from(cl.weight)       # data parallel: the gradient exchange starts on finished arena ranges while backward runs on
         ops.conv3x3(h=H, w=W, cin=ws.g8.shape[-1], cout=nf, inp=V(ws.g8), out=V(ws.gUH), wpacked=pk["last"][1], mask=V(ws.UH),
                     mask_slope=SLOPE, **K)
         ch = getattr(m, str(self._idx_hr))
         top = ws.U[self.n_up]
         wgrad(ch, V(top), V(ws.gUH), H, W)
+        self._grads_final_from(ch.weight)
         if self.n_up == 0:
             ops.conv3x3(h=H, w=W, cin=nf, cout=nf, inp=V(ws.gUH), out=V(ws.gT32), out2=V(ws.gT), wpacked=pk["hr"][1], **K)
         else:
@@ -334,6 +336,7 @@ class RRDBNet(FlatParamModule):
             cu = getattr(m, str(idx + 1))
             hj, wj = h << j, w << j
             wgrad(cu, V(ws.U[j - 1]), V(ws.gU[j]), hj, wj, in_mode=L.IN_NEAREST2X)
+            self._grads_final_from(cu.weight)
             ops.conv3x3(h=hj, w=wj, cin=nf, cout=nf, inp=V(ws.gU[j]), out=V(ws.gTmp[j]), wpacked=pk[("up", j - 1)][1], **K)
             if j > 1:
                 ops.sumpool2x2(V(ws.gTmp[j]), V(ws.gU[j - 1]), V(ws.U[j - 1]), SLOPE, n, hj, wj)
@@ -344,6 +347,7 @@ class RRDBNet(FlatParamModule):
         sub = getattr(m, "1").sub
         ct = getattr(sub, str(nb))
         wgrad(ct, V(ws.T), V(ws.gT), h, w)
+        self._grads_final_from(ct.weight)
         G = ws.G
         cur = 0
         g_z = ws.GS[0]
@@ -382,6 +386,7 @@ class RRDBNet(FlatParamModule):
                     convs.append(dict(cin=cv.cin, cout=cv.cout, inp=V(xb, 0, cv.cin), gy=V(g, goff, cv.cout), dw=cv.weight.grad, db=cv.bias.grad,
                                       workspace=ws.wg5[c - 1]))
                 ops.wgrad3x3_multi(convs, n=n, h=h, w=w, compute=cd, accumulate=True)
+                self._grads_final_from(getattr(rdb.conv1, "0").weight)      # conv1 is the block's first parameter in the arena
                 g_y = g_next
                 cur ^= 1
             g_z = g_y

@@ -29,7 +29,7 @@ from .. import ops
 from ..archs import build_network
 from ..losses import build_loss
 from ..optimizers import AdamW, build_optimizer
-from ..utils.dist_util import allreduce_flat_, get_dist_info, master_only
+from ..utils.dist_util import GradExchange, get_dist_info, master_only
 from ..utils.misc import loss_type_to_label
 from .ema import EMA
 
@@ -269,6 +269,15 @@ class SRModel:
     def get_bare_model(self, net):
         return net
 
+    def _exchange(self, net) -> GradExchange:
+        """The (cached) bucketed gradient exchange of a flat-arena network; rebuilt when the arena moved."""
+        _, garr = net.flat_parameters()
+        ex = getattr(net, "grad_exchange", None)
+        if ex is None or ex.flat.data_ptr() != garr.data_ptr() or ex.flat.numel() != garr.numel():
+            ex = GradExchange(garr, bucket_bytes=int(os.environ.get("TRAINNER_BUCKET_MB", "24")) << 20)
+            net.grad_exchange = ex
+        return ex
+
     def get_current_learning_rate(self) -> list[float]:
         return [g["lr"] for g in self.optimizers[0].param_groups]
 
@@ -415,23 +424,26 @@ class SRModel:
         idx = list(range(nloss)) + [TOTAL]
         keys.append("l_g_total")
 
+        rank, world = get_dist_info()
         if hip_net:
             if self._yuv_out:
                 gout = ops.color601(gout, 2)     # d loss / d(RGB) -> d loss / d(YCbCr network output)
+            # data parallel (DDP's reducer, base_model.py:228-234): the gradient arena is exchanged in a few large buckets, each launched by
+            # backward_hip as soon as the parameters it covers are final.  Only on steps that apply the gradient: with accum_iter > 1 the
+            # micro-steps accumulate locally (the reference reduces on every micro-batch because it never uses no_sync -- same result).
+            ex_g = self._exchange(net) if (world > 1 and apply_gradient) else None
+            if ex_g is not None:
+                ex_g.begin()
             if hasattr(net, "train_backward"):
                 net.train_backward(gout)
             else:
                 net.backward_hip(gout)
 
-        rank, world = get_dist_info()
         if apply_gradient:
             if hip_net:
                 parr, garr = net.flat_parameters()
-                if world > 1:
-                    allreduce_flat_(garr)
-                    # DDP averages: fold 1/world into the arena once (tiny vs the step)
-                    gv = garr.view(-1, 4)
-                    ops.axpby(ops.view(gv), 1.0 / world, ops.NULL_VIEW, 0.0, ops.view(gv), gv.shape[0])
+                if ex_g is not None:
+                    ex_g.finish()                # remaining buckets, wait, 1/world (DDP averages)
                 ops.sumsq_norm(garr, scal[GN_G:GN_G + 1])
                 self._gnorm = scal[GN_G:GN_G + 1]
                 # sr_model.py:665-666 raises on a non-finite l_g_total before backward; the total lives on the device here, so it poisons the
@@ -508,10 +520,10 @@ class SRModel:
                 idx += [LD_REAL, LD_FAKE]
                 if apply_gradient:
                     parr_d, garr_d = dnet.flat_parameters()
-                    if world > 1:
-                        allreduce_flat_(garr_d)
-                        gv = garr_d.view(-1, 4)
-                        ops.axpby(ops.view(gv), 1.0 / world, ops.NULL_VIEW, 0.0, ops.view(gv), gv.shape[0])
+                    if world > 1:                   # the discriminator's arena (17.5 MB for UNetDiscriminatorSN): one bucket after its two backward passes
+                        ex_d = self._exchange(dnet)
+                        ex_d.begin()
+                        ex_d.finish()
                     ops.sumsq_norm(garr_d, scal[GN_D:GN_D + 1])
                     keys.append("grad_norm_d")
                     idx.append(GN_D)
