@@ -123,3 +123,54 @@ def test_fp16_step_with_loss_scaling_and_overflow_skip(cuda):
         assert torch.equal(v, before[k]), k
     g_arena = model.net_g.flat_parameters()[1]
     assert float(g_arena.abs().sum()) == 0.0           # the overflowed gradients are dropped, not accumulated
+
+
+def test_span_2x_fp16_loss_scaled_training_step(cuda):
+    """BASELINE.json configs[4]: SPAN 2x (52 feature channels, the `span` preset of archs/span_arch.py:326-346), fp16 AMP with loss scaling, through
+    `SRModel.optimize_parameters`: the step with scale 65536 lands where the f16-policy oracle's step lands (loss value, unscaled gradient norm,
+    update direction of the first AdamW step), the scaler keeps its scale on a clean step, and a second step keeps everything finite."""
+    from oracle import losses as OL, span as OSP, step as OS
+    from oracle.precision import F16_OPS
+    from tests.test_sr_model_gpu import _opt
+    from trainner_redux_amd.models import SRModel
+
+    opt = _opt([dict(type="l1loss", loss_weight=1.0)], use_amp=True, network_g=dict(type="span", norm=False))
+    opt.amp_bf16 = False
+    opt.scale = 2
+    model = SRModel(opt)
+    assert model.compute_dtype == torch.float16 and model.scaler_g.enabled and model.net_g.compute_dtype == torch.float16
+    hp = OSP.hparams(feature_channels=52, scale=2, norm=False)
+    g0 = torch.Generator().manual_seed(3)
+    sd = OrderedDict((k, torch.randn(shp, generator=g0) * (0.05 if len(shp) == 1 else (1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5)))
+                     for k, shp in OSP.param_table(hp).items() if "eval_conv" not in k)
+    assert sum(v.numel() for v in sd.values()) + sum(p.numel() for k, p in model.net_g.named_parameters() if "eval_conv" in k) == 2_605_080      # docs/source/benchmarks.md:209
+    res = model.net_g.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all("eval_conv" in k for k in res.missing_keys)
+    g = torch.Generator().manual_seed(12)
+    gt = torch.rand(4, 3, 64, 64, generator=g)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.5, mode="bicubic", antialias=True).clamp(0, 1)
+    fwd = lambda p, x: OSP.forward(p, x, hp, F16_OPS, train=True)  # noqa: E731
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost = OS.AdamWState(OrderedDict((k, v.data) for k, v in params.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    _, ld, _, _ = OS.generator_step(params, fwd, OrderedDict(l_g_l1=(OL.l1, 1.0)), lq, gt, ost, None)
+    # the update direction from a SCALED loss, as the scaler produces it (unscaled fp16 gradients sit in the subnormals); Adam's first step is scale-invariant
+    params2 = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    ost2 = OS.AdamWState(OrderedDict((k, v.data) for k, v in params2.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    _, ld2, _, _ = OS.generator_step(params2, fwd, OrderedDict(l_g_l1=(lambda o, t: OL.l1(o, t) * 65536.0, 1.0)), lq, gt, ost2, None)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    assert not model.optimizers_skipped[0] and model.scaler_g.scale == 65536.0
+    assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 2e-3 * float(ld["l_g_l1"]), (log["l_g_l1"], float(ld["l_g_l1"]))
+    gn_ref = float(ld2["grad_norm_g"]) / 65536.0
+    assert abs(log["grad_norm_g"] - gn_ref) < 0.05 * gn_ref, (log["grad_norm_g"], gn_ref)      # logged after unscale_ (sr_model.py:688-705)
+    sdm = model.net_g.state_dict()
+    big = [k for k, v in sd.items() if v.ndim == 4 and v.shape[-1] == 3]                       # the 3x3 kernels carry most of the update
+    moved = max(rel_l2(sdm[k].detach().cpu() - sd[k], params2[k].data - sd[k]) for k in big)
+    cos = min(cosine(sdm[k].detach().cpu() - sd[k], params2[k].data - sd[k]) for k in big)
+    print(f"span 2x fp16 step: loss {log['l_g_l1']:.6f} (oracle {float(ld['l_g_l1']):.6f}); update direction rel-L2 {moved:.3f}, min cosine {cos:.4f}")
+    assert moved < 0.35 and cos > 0.93          # sign flips of near-zero gradients dominate a first Adam step (tests/test_sr_model_gpu.py)
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(2, 0, True)
+    log2 = model.get_current_log()
+    assert all(v == v and abs(v) < 1e6 for v in log2.values()) and torch.isfinite(model.net_g.flat_parameters()[0]).all()

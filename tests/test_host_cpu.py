@@ -273,3 +273,58 @@ def test_mfma_kernels_keep_accumulators_in_registers():
         return 0 if "wgrad_ring" in name else 96
     bad = {k: v["scratch"] for k, v in r2.items() if v.get("scratch", 0) > limit2(k)}
     assert not bad, bad
+
+
+def test_update_learning_rate_warmup_ramp_and_skipped_step_gating():
+    """`SRModel.update_learning_rate` (reference: models/base_model.py:369-390, called once per applied step by train.py:854-857) on the host, next
+    to the reference's rule spelled out on torch's own MultiStepLR: every call steps the scheduler of each optimizer whose AMP step was NOT skipped,
+    then -- while current_iter < warmup_iter -- sets lr = initial_lr / warmup_iter * current_iter.  (torch's chainable MultiStepLR derives the next lr
+    from the group's CURRENT lr, so the warm-up override and the skipped steps both leave traces in later values: the sequences must match call
+    for call, not just at the end.)"""
+    import torch
+
+    from trainner_redux_amd.models.sr_model import SRModel
+
+    def pair():
+        ps = [torch.nn.Parameter(torch.zeros(2))]
+        og, od = torch.optim.AdamW(ps, lr=2e-4), torch.optim.AdamW([torch.nn.Parameter(torch.zeros(2))], lr=1e-4)
+        return [og, od], [torch.optim.lr_scheduler.MultiStepLR(o, milestones=[3, 6, 9], gamma=0.5) for o in (og, od)]
+
+    class Fake:                      # the attributes the method reads; the trainer itself needs a GPU to construct
+        pass
+
+    me = Fake()
+    me.optimizers, me.schedulers = pair()
+    me._init_lr = [[g["lr"] for g in o.param_groups] for o in me.optimizers]
+    me.use_amp = True
+    me.optimizers_skipped = [False, False]
+    ref_opts, ref_scheds = pair()
+    warm = 5
+    skipped_at = {4: (True, False), 7: (False, True), 8: (True, True)}      # loss-scaler overflows: G only, D only, both
+    seen = []
+    for it in range(1, 13):
+        sk = skipped_at.get(it, (False, False))
+        me.optimizers_skipped = list(sk)
+        SRModel.update_learning_rate(me, it, warm)
+        for i, sch in enumerate(ref_scheds):                                  # base_model.py:377-379
+            if not sk[i]:
+                sch.step()
+        if it < warm:                                                         # :381-390
+            for o in ref_opts:
+                for g in o.param_groups:
+                    g["lr"] = g["initial_lr"] / warm * it
+        got = [o.param_groups[0]["lr"] for o in me.optimizers]
+        want = [o.param_groups[0]["lr"] for o in ref_opts]
+        assert got == want, (it, got, want)
+        seen.append(got[0])
+    assert seen[0] == 2e-4 / 5 and seen[1] == 2e-4 / 5 * 2 and seen[3] == 2e-4 / 5 * 4          # the ramp (iterations 1, 2, 4)
+    assert [s.last_epoch for s in me.schedulers] == [10, 10]                                   # 12 calls, two skipped per optimizer
+    assert SRModel.get_current_learning_rate(me) == [seen[-1]]
+    # no warm-up (warmup_iter = -1, the default): plain MultiStepLR
+    me2 = Fake()
+    me2.optimizers, me2.schedulers = pair()
+    me2._init_lr = [[2e-4], [1e-4]]
+    me2.use_amp, me2.optimizers_skipped = False, [False, False]
+    for it in range(1, 8):
+        SRModel.update_learning_rate(me2, it)
+    assert abs(me2.optimizers[0].param_groups[0]["lr"] - 2e-4 * 0.25) < 1e-12            # two milestones (3, 6) passed after 7 steps

@@ -282,11 +282,11 @@ class SRModel:
         return [g["lr"] for g in self.optimizers[0].param_groups]
 
     def update_learning_rate(self, current_iter: int, warmup_iter: int = -1) -> None:
-        # base_model.py:369-390: schedulers advance unless that optimizer's step was skipped; linear warm-up
-        if current_iter > 1:
-            for i, s in enumerate(self.schedulers):
-                if not (self.use_amp and self.optimizers_skipped[i]):
-                    s.step()
+        # base_model.py:369-390: every call steps every scheduler unless that optimizer's AMP step was skipped (optimizers_skipped is only ever set by a
+        # loss-scaler overflow), then the linear warm-up overrides the groups' lr from their INITIAL lr
+        for i, s in enumerate(self.schedulers):
+            if not self.optimizers_skipped[i]:
+                s.step()
         if current_iter < warmup_iter and self.schedulers:
             for o, init in zip(self.optimizers, self._init_lr):
                 for g, lr0 in zip(o.param_groups, init):
