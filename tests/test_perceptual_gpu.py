@@ -14,8 +14,10 @@ def rel_l2(a, b):
 
 
 @pytest.mark.parametrize("criterion", ["charbonnier", "l1"])
-@pytest.mark.parametrize("name,dtype,tol_v,tol_g", [("perceptualloss", torch.bfloat16, 2e-5, 2e-4), ("perceptualfp16loss", torch.bfloat16, 5e-3, 5e-2)])
-def test_perceptual_value_and_grad(cuda, criterion, name, dtype, tol_v, tol_g):
+@pytest.mark.parametrize("name,dtype,tol_v,tol_g,wino", [("perceptualloss", torch.bfloat16, 2e-5, 2e-4, "1"), ("perceptualloss", torch.bfloat16, 2e-5, 2e-4, "2"),
+                                                       ("perceptualloss", torch.bfloat16, 2e-5, 2e-4, "0"), ("perceptualfp16loss", torch.bfloat16, 5e-3, 5e-2, "1")])
+def test_perceptual_value_and_grad(cuda, criterion, name, dtype, tol_v, tol_g, wino, monkeypatch):
+    monkeypatch.setenv("TRAINNER_VGG_WINOGRAD", wino)       # "1": F(4x4,3x3) + fused pool epilogues (default); "2": F(2x2,3x3); "0": direct fp32 MFMA convs
     from oracle import vgg as OV
     from oracle.precision import BF16_OPS, FP32
     from trainner_redux_amd.losses import build_loss
@@ -55,10 +57,18 @@ def test_perceptual_value_and_grad(cuda, criterion, name, dtype, tol_v, tol_g):
     # that rare; bf16 operands (4e-3) make it routine, so the bf16 head is held to direction (cosine), not to rounding.
     if dtype == torch.bfloat16 and name != "perceptualloss":
         assert cos > 0.97 and e < 0.3, (cos, e)
+    elif wino != "1":
+        # fp32 head on the F(2x2, 3x3) / direct kernels (4e-7 of rounding noise per layer): no window flips on this draw, the gradient is held to the
+        # rounding-level bound (measured 5e-5).  Same program, same pool / loss kernels as the default path apart from the fused-pool epilogues.
+        assert e < tol_g and cos > 0.999999, (cos, e)
     else:
-        # fp32 head: the F(4x4, 3x3) Winograd convs carry ~2e-6 of rounding noise per layer (F(2x2): 4e-7, TRAINNER_VGG_WINOGRAD=2), enough to flip the
-        # odd near-tied window on this draw (measured 1.2e-3 with cosine 1.00000; 5e-5 with the F(2x2) kernels): direction to 1e-5, size to 5e-3
-        assert cos > 0.99999 and e < max(tol_g, 5e-3), (cos, e)
+        # fp32 head, default path: the F(4x4, 3x3) Winograd convs carry ~2e-6 of rounding noise per layer, enough to flip the odd near-tied 2x2
+        # window on this draw, which re-routes one gradient path (measured rel-L2 1.2e-3, cosine 1.00000).  A flip is LOCAL (one receptive field);
+        # a routing / mask bug in the pool-fused epilogue or in tr_pixel_loss_pool_bwd would be everywhere.  So: direction to 1e-5, size to 5e-3, and
+        # all but a small fraction of the elements at rounding level.
+        off = ((grad.cpu() - gref).abs() > 2e-4 * gref.abs().max()).float().mean().item()
+        print(f"  elements off by more than 2e-4 of the largest gradient: {off:.4f}")
+        assert cos > 0.99999 and e < 5e-3 and off < 0.02, (cos, e, off)
     g1 = grad.clone()
     # accumulate form: a second call adds onto the existing gradient
     loss.hip_value_and_grad(xd, gtd, value_weight=w, value_out=vals, total_weight=0.0, total_out=None, grad_weight=w * acc, grad=grad,

@@ -471,3 +471,94 @@ def test_yuv444_pixel_format_matches_reference_colour_functions_and_trains(cuda)
     assert abs(log["l_g_l1"] - float(ld["l_g_l1"])) < 1e-5 * float(ld["l_g_l1"])
     e_w = max(rel_l2(model.net_g.state_dict()[k].detach().cpu(), v.data) for k, v in params.items())
     assert e_w < 5e-4, e_w
+
+
+def test_configs2_composite_step_on_an_otf_pair_matches_oracle(cuda):
+    """BASELINE.json configs[2] as ONE step: RealESRGANModel.feed_data degrades a GT batch on the device (lens distortion, blur, sensor noise,
+    exposure, resize, sinc filter, a JPEG round trip on the host, 8-bit rounding, paired crop), then `optimize_parameters` runs the ESRGAN generator
+    with L1 + perceptual (fp32 VGG19, dict-valued) + vanilla GAN through UNetDiscriminatorSN and the discriminator update -- checked against the oracle
+    pieces composed in the reference's order (sr_model.py:452-828) on the very pair the feed produced: every log value, G / D weights after their AdamW
+    steps, spectral-norm u / v after the three power iterations."""
+    import warnings
+
+    from oracle import discriminator as OD, esrgan as OE, losses as OL, step as OS, vgg as OV
+    from trainner_redux_amd.models import RealESRGANModel, build_model
+    from trainner_redux_amd.utils.options import parse_options_dict
+
+    wg, wp = 0.1, 0.01
+    opt = parse_options_dict(dict(
+        name="c2", scale=4, num_gpu=1, path={}, manual_seed=11, use_amp=False, high_order_degradation=True, queue_size=2,
+        lens_distort_prob=1.0, blur_prob=1.0, sensor_noise_prob=1.0, exposure_prob=1.0, resize_mode_list3=["bicubic"], resize_mode_prob3=[1.0],
+        compression_formats=["jpeg"], compression_weights=[1.0],
+        network_g=dict(type="esrgan", num_blocks=1), network_d=dict(type="unetdiscriminatorsn", num_in_ch=3, num_feat=16, skip_connection=True),
+        datasets=dict(train=dict(name="x", type="realesrgandataset", lq_size=16, batch_size_per_gpu=2)),
+        train=dict(total_iter=100, ema_decay=0.999, ema_power=0.75, optim_g=dict(type="AdamW", lr=2e-4, weight_decay=0, betas=[0.9, 0.99]),
+                   optim_d=dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99]),
+                   losses=[dict(type="l1loss", loss_weight=1.0), dict(type="perceptualloss", loss_weight=wp, criterion="charbonnier"),
+                           dict(type="ganloss", gan_type="vanilla", loss_weight=wg)])))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = build_model(opt)
+    assert isinstance(model, RealESRGANModel)
+    hp = OE.esrgan_hparams(scale=4, num_blocks=1)
+    sd = OE.init_state_dict(hp, 3)
+    vsd = OV.synthetic_state_dict(7)
+    model.net_g.load_state_dict(sd)
+    model.losses["l_g_perceptual"].vgg.load_torchvision_state_dict(vsd)
+    dsd = {k: v.detach().cpu().clone() for k, v in model.net_d.state_dict().items()}
+    g = torch.Generator().manual_seed(21)
+    gt_full = torch.rand(2, 3, 96, 96, generator=g)
+    k1 = torch.rand(2, 21, 21, generator=g)
+    k1 = k1 / k1.sum((1, 2), keepdim=True)
+    sinc = torch.zeros(2, 21, 21)
+    sinc[:, 10, 10] = 1.0
+    model.feed_data({"gt": gt_full, "kernel1": k1, "kernel2": k1, "sinc_kernel": sinc})
+    lq, gt = model.lq.cpu().clone(), model.gt.cpu().clone()
+    assert lq.shape == (2, 3, 16, 16) and gt.shape == (2, 3, 64, 64) and torch.equal(lq, (lq * 255).round() / 255)
+    assert 0.02 < (lq - torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True)).abs().mean() < 0.5      # really degraded
+
+    gp = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    dkeys = [k for k in dsd if not k.endswith(("weight_u", "weight_v"))]
+    dp = OrderedDict((k, dsd[k].clone().requires_grad_(True)) for k in dkeys)
+    state = dict(dsd)
+
+    def dnet(x):
+        cur = {**state, **dp}
+        y, uv = OD.forward(cur, x, training=True)
+        for name, (u, v) in uv.items():
+            state[f"{name}.weight_u"], state[f"{name}.weight_v"] = u, v
+        return y
+
+    out = OE.forward(gp, lq, hp)
+    l1 = OL.l1(out, gt)
+    perc = OV.perceptual_loss(vsd, out, gt)
+    lgan = OL.gan(dnet(out), True, is_disc=False)
+    total = l1 * 1.0 + sum(v * wp for v in perc.values()) + lgan * wg          # accum_iters = 1: scalar / dict scaling coincide (sr_model.py:654-663)
+    gg = torch.autograd.grad(total, list(gp.values()))
+    ogs = OS.AdamWState(OrderedDict((k, v.data) for k, v in gp.items()), lr=2e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    ogs.step(OrderedDict((k, v.data) for k, v in gp.items()), OrderedDict(zip(gp.keys(), gg)))
+    ldr = OL.gan(dnet(gt), True, is_disc=True)
+    ldf = OL.gan(dnet(out.detach()), False, is_disc=True)
+    dg = torch.autograd.grad((ldr + ldf) * wg, list(dp.values()))
+    ods = OS.AdamWState(OrderedDict((k, v.data) for k, v in dp.items()), lr=1e-4, betas=(0.9, 0.99), weight_decay=0.0)
+    ods.step(OrderedDict((k, v.data) for k, v in dp.items()), OrderedDict(zip(dp.keys(), dg)))
+
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    want = {"l_g_l1": l1, "l_g_gan": lgan * wg, "l_g_total": total, "l_d_real": ldr, "l_d_fake": ldf}
+    want.update({f"l_g_perceptual_{k}": v * wp for k, v in perc.items()})
+    assert set(want) | {"grad_norm_g", "grad_norm_d"} <= set(log), set(log)
+    for k, ref in want.items():
+        assert abs(log[k] - float(ref)) < 3e-5 * abs(float(ref)), (k, log[k], float(ref))
+    gn = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(t, 2) for t in gg]))
+    assert abs(log["grad_norm_g"] - float(gn)) < 1e-4 * float(gn)
+    # first moments (0.1 x gradient) are the rounding-tight comparison; the weights carry AdamW's first-step sign sensitivity (see above)
+    og = model.optimizers[0]
+    m = {k: og.state[p]["exp_avg"].cpu() for k, p in model.net_g.named_parameters()}
+    e_m = max(rel_l2(m[k], ogs.m[k]) for k in gp)
+    e_g = max(rel_l2(p.detach().cpu(), gp[k].data) for k, p in model.net_g.state_dict().items())
+    dnow = model.net_d.state_dict()
+    e_d = max(rel_l2(dnow[k].cpu(), dp[k].data) for k in dkeys)
+    e_uv = max(rel_l2(dnow[k].cpu(), state[k]) for k in dsd if k.endswith(("weight_u", "weight_v")))
+    print(f"configs[2] composite step: G first moments {e_m:.2e}, G weights {e_g:.2e}, D weights {e_d:.2e}, u/v {e_uv:.2e}")
+    assert e_m < 2e-4 and e_g < 5e-4 and e_d < 5e-4 and e_uv < 1e-5

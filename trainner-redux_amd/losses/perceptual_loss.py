@@ -241,6 +241,7 @@ class VGG(nn.Module):
         flip = 0
         fuse_pool = not os.environ.get("TRAINNER_NO_POOL_FUSION")
         pooled = None           # output of the pool op that the previous conv has already written (Winograd F(4,3) epilogue)
+        ws.pop("_pool_view", None)      # per pass: the marker of "this conv's input is the shared pooled scratch"
         for k, op in enumerate(self.program):
             if op[0] == "conv":
                 _, name, m, fused_relu, tapped = op
@@ -252,7 +253,8 @@ class VGG(nn.Module):
                     out = ws["scratch"][flip].view(-1)[: n * hh * ww * m.cout].view(n, hh, ww, m.cout)
                     flip ^= 1
                 wino = len(pk[name]) > 2 and not first and hh % 2 == 0 and ww % 2 == 0
-                w43 = wino and len(pk[name]) > 4 and hh % 4 == 0 and ww % 4 == 0
+                w43 = wino and len(pk[name]) > 4 and ops.winograd43_eligible(cur_c, m.cout, hh, ww, cur.shape[-1], out.shape[-1])
+                wino = wino and (w43 or ops.winograd_eligible(cur_c, m.cout, hh, ww))      # an ineligible layer / size falls back: F(4,3) -> F(2,2) -> direct
                 if first and stem:
                     ops.conv3x3_stem(img.contiguous(), m.weight.data, m.bias.data, V(out), mean=IMAGENET_MEAN, std=IMAGENET_STD, pad_mode=L.PAD_REPLICATE,
                                      act=L.ACT_RELU if fused_relu else L.ACT_NONE)
@@ -371,7 +373,8 @@ class VGG(nn.Module):
             gin = dst_buf.view(-1)[: inp_act.numel()].view(inp_act.shape)
             mask = V(inp_act) if (prev[0] == "conv" and prev[3]) else ops.NULL_VIEW
             wino = len(pk[name]) > 2 and hh % 2 == 0 and ww % 2 == 0
-            w43 = wino and len(pk[name]) > 4 and hh % 4 == 0 and ww % 4 == 0
+            w43 = wino and len(pk[name]) > 4 and ops.winograd43_eligible(m.cout, m.cin, hh, ww, g.shape[-1], gin.shape[-1])
+            wino = wino and (w43 or ops.winograd_eligible(m.cout, m.cin, hh, ww))
             ops.conv3x3(n=n, h=hh, w=ww, cin=m.cout, cout=m.cin, compute=L.F32_WINOGRAD43 if w43 else L.F32_WINOGRAD if wino else cd, inp=V(g), out=V(gin),
                         wpacked=pk[name][5 if w43 else 3 if wino else 1], mask=mask, mask_slope=0.0)
             g = gin

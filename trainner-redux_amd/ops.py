@@ -137,8 +137,12 @@ def pack_winograd(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor
     return dst
 
 
-def winograd43_eligible(cin: int, cout: int, h: int, w: int) -> bool:
-    return cin % 8 == 0 and cin > 32 and cout % 64 == 0 and h % 4 == 0 and w % 4 == 0      # more than four 8-channel chunks: the halo stream's lookahead
+def winograd43_eligible(cin: int, cout: int, h: int, w: int, cstride_in: int | None = None, cstride_out: int | None = None) -> bool:
+    """The limits tr_conv3x3_winograd43_f32 TR_REQUIREs: more than four 8-channel chunks (the halo stream's lookahead), 64-wide output groups,
+    H and W multiples of 4, one fp32 image of either view below the 2 GiB of buffer addressing."""
+    img = h * w * 4
+    return cin % 8 == 0 and cin > 32 and cout % 64 == 0 and h % 4 == 0 and w % 4 == 0 and \
+        img * (cstride_in or cin) < 0x7fff0000 and img * (cstride_out or cout) < 0x7fff0000
 
 
 def pack_winograd43(weight: torch.Tensor, transpose: bool = False) -> torch.Tensor:
