@@ -11,9 +11,8 @@ torch.manual_seed(0)
 
 
 def run(impl, cfg, n, h, w, cin, cout, form, dt=torch.bfloat16, cd=L.BF16, up=False, bufs=None):
-    os.environ["TRAINNER_CONV_IMPL"] = impl
-    if cfg is None: os.environ.pop("TRAINNER_RING_CFG", None)
-    else: os.environ["TRAINNER_RING_CFG"] = str(cfg)
+    ops.tune_set("conv_impl", {"reg": 1, "ring": 2}[impl])        # tr_tune_set (round 3: launches no longer read the environment)
+    ops.tune_set("ring_cfg", -1 if cfg is None else cfg)
     x, wbuf, bias, mk, r1, r2 = bufs
     cs = x.shape[-1]
     out_dt = torch.float32 if form in ("res1", "res2") else dt

@@ -19,7 +19,7 @@ def mk(n, h, w, cin, cout, dt, up=False):
 
 
 def run(impl, n, h, w, cin, cout, cd, bufs, up=False, accumulate=False):
-    os.environ["TRAINNER_WGRAD_IMPL"] = impl
+    ops.tune_set("wgrad_impl", {"reg": 1, "ring": 2}.get(impl, 0))
     x, gy, ws = bufs
     dw = torch.full((cout, cin, 3, 3), 0.5, device=dev)
     db = torch.full((cout,), 0.25, device=dev)
@@ -91,8 +91,8 @@ def multi():
         wss = [torch.empty(need // 4 + 16, dtype=torch.float32, device=dev) for _ in range(5)]
 
         def run(fused):
-            os.environ["TRAINNER_WGRAD_IMPL"] = "ring"
-            os.environ["TRAINNER_WGRAD_MULTI"] = "1" if fused else "0"
+            ops.tune_set("wgrad_impl", 2)
+            ops.tune_set("wgrad_multi", 1 if fused else 0)
             dws = [torch.full((co, ci, 3, 3), 0.5, device=dev) for ci, co, _ in shapes]
             dbs = [torch.full((co,), 0.25, device=dev) for ci, co, _ in shapes]
             convs = [dict(cin=ci, cout=co, inp=ops.view(xb, 0, ci), gy=ops.view(g, go, co), dw=dws[k], db=dbs[k], workspace=wss[k]) for k, (ci, co, go) in enumerate(shapes)]

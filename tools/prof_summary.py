@@ -45,9 +45,34 @@ def pmc_all(d):
         out.append(f"{key[0]:48s} grid {key[1]:>8s} lds {key[2]:>6s} launches {n:4d} | " + "  ".join(f"{c}={cs[c] / n:.3e}" for c in sorted(names)))
     return "\n".join(out)
 
+def mfma_busy(d):
+    """MFMA utilisation per kernel from a `--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE ...` pass:
+    util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)  (the gfx94x MfmaUtil formula; rocprofv3 sums GRBM over the XCDs);
+    clock = GRBM_GUI_ACTIVE / 8 / kernel wall time (MI355X_MICROARCH.md, DVFS give-back)."""
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen, dur = collections.defaultdict(set), collections.defaultdict(float)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])[:70]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen[k]:
+            seen[k].add(r["Dispatch_Id"])
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    out = [f"{'kernel':70s} {'calls':>6s} {'avg_us':>9s} {'MFMA_BUSY/launch':>17s} {'GUI_ACTIVE/8':>13s} {'mfma_util':>9s} {'clock_GHz':>9s} {'MFMA_MOPS/launch':>17s}"]
+    for k in sorted(agg, key=lambda k: -dur[k])[:16]:
+        c, n = agg[k], len(seen[k])
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8
+        mf = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        mops = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0) + c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0)
+        out.append(f"{k:70s} {n:6d} {dur[k] / n:9.1f} {mf / n:17.3e} {gui / n:13.3e} {(mf / (gui * 1024) if gui else 0):9.3f} {(gui / dur[k] / 1e3 if dur[k] else 0):9.2f} {mops / n:17.3e}")
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    if cmd == "pmcall":
+    if cmd == "mfma":
+        print(mfma_busy(sys.argv[2]))
+    elif cmd == "pmcall":
         print(pmc_all(sys.argv[2]))
     elif cmd == "stats":
         print(kernel_stats(sys.argv[2]))

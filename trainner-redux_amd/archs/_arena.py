@@ -12,7 +12,7 @@ import copy
 import torch
 from torch import nn
 
-_TRANSIENT = ("_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist", "_frozen_arena", "_offset_of", "grad_exchange")
+_TRANSIENT = ("_keep_state", "_ws", "_saved", "_plan", "_pk", "_trigger", "_arena", "_grad_arena", "_offsets", "_slabs", "_gs", "_plist", "_frozen_arena", "_offset_of", "grad_exchange")
 
 
 class FlatParamModule(nn.Module):
@@ -156,8 +156,10 @@ class FlatParamModule(nn.Module):
     def _graphs_on(self) -> bool:
         import os
 
-        return bool(self.hip_graphs or os.environ.get("TRAINNER_HIP_GRAPHS") == "1") and getattr(self, "drop_path", 0.0) == 0.0 and \
-            getattr(self, "drop_path_rate", 0.0) == 0.0
+        # stochastic depth: only networks whose keep masks are drawn on the device into fixed buffers inside forward_hip (SwinIR: the draw is
+        # captured with the step and torch advances the generator's offset on every replay) may replay; host-drawn masks are per-step operands
+        dp = max(float(getattr(self, "drop_path", 0.0) or 0.0), float(getattr(self, "drop_path_rate", 0.0) or 0.0))
+        return bool(self.hip_graphs or os.environ.get("TRAINNER_HIP_GRAPHS") == "1") and (dp == 0.0 or getattr(self, "graph_safe_drop_path", False))
 
     def train_forward(self, x: torch.Tensor) -> torch.Tensor:
         """forward_hip(x, train=True), replayed from a hipGraph once the step has run GRAPH_WARMUP times with this geometry."""

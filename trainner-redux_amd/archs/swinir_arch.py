@@ -133,6 +133,8 @@ class _PE(nn.Module):
 
 
 class SwinIR(FlatParamModule):
+    graph_safe_drop_path = True       # `_keep_masks` draws on the device into persistent buffers: a hipGraph of the step re-draws on every replay
+
     def __init__(self, *, upscale=4, img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths: Sequence[int] = (6,) * 6,
                  num_heads: Sequence[int] = (6,) * 6, window_size=8, mlp_ratio=2.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0,
                  drop_path_rate=0.1, ape=False, patch_norm=True, use_checkpoint=False, img_range=1.0, upsampler="pixelshuffle",
@@ -229,15 +231,24 @@ class SwinIR(FlatParamModule):
 
     # ------------------------------------------------------------------ forward ------------------------------------------------
     def _keep_masks(self, b, dev):
-        """DropPath (drct_arch.py:572-573): per block and sample, keep/(1-p) with p rising linearly over the blocks."""
+        """DropPath (drct_arch.py:572-573): per block and sample, keep/(1-p) with p rising linearly over the blocks.
+
+        ONE draw for all blocks into a persistent (blocks x batch) buffer (three launches per step instead of four per block), rows handed out as
+        views: the addresses stay fixed from step to step, so a captured hipGraph of the step reads this step's masks (archs/_arena.py)."""
         nblk = sum(self.depths)
-        rates = torch.linspace(0, self.drop_path_rate, nblk).tolist()
+        st = self.__dict__.get("_keep_state")
+        if st is None or st["key"] != (b, str(dev), nblk, self.drop_path_rate):
+            rates = torch.linspace(0, self.drop_path_rate, nblk)
+            st = self._keep_state = dict(key=(b, str(dev), nblk, self.drop_path_rate), rates=rates.tolist(), p=rates.to(dev).view(nblk, 1),
+                                         inv=(1.0 / (1.0 - rates)).to(dev).view(nblk, 1), u=torch.empty(nblk, b, device=dev), keep=torch.empty(nblk, b, device=dev))
+        st["u"].uniform_()                                   # same distribution as the reference's per-block rand(); one stream instead of 36
+        torch.ge(st["u"], st["p"], out=st.setdefault("ge", torch.empty(nblk, b, dtype=torch.bool, device=dev)))
+        torch.mul(st["ge"], st["inv"], out=st["keep"])
         out, k = {}, 0
         for i, j, _, _ in self._blocks():
-            p = rates[k]
+            if st["rates"][k] > 0:
+                out[(i, j)] = st["keep"][k]
             k += 1
-            if p > 0:
-                out[(i, j)] = (torch.rand(b, device=dev) >= p).float() / (1.0 - p)
         return out
 
     def forward_hip(self, x: torch.Tensor, train: bool | None = None, keep_masks: dict | None = None) -> torch.Tensor:
