@@ -562,3 +562,31 @@ def test_configs2_composite_step_on_an_otf_pair_matches_oracle(cuda):
     e_uv = max(rel_l2(dnow[k].cpu(), state[k]) for k in dsd if k.endswith(("weight_u", "weight_v")))
     print(f"configs[2] composite step: G first moments {e_m:.2e}, G weights {e_g:.2e}, D weights {e_d:.2e}, u/v {e_uv:.2e}")
     assert e_m < 2e-4 and e_g < 5e-4 and e_d < 5e-4 and e_uv < 1e-5
+
+
+def test_negative_loss_weight_selects_the_bicubic_lq_target(cuda):
+    """sr_model.py:503-516: `loss_weight < 0` makes that loss compare the output with clamp(bicubic-antialias upsample of LQ) instead of GT, weighted by
+    |loss_weight|; the other losses keep GT.  One fp32 step against the oracle's step with the same two targets."""
+    from oracle import esrgan as OE, losses as OL, step as OS
+    from trainner_redux_amd.models import SRModel
+
+    model = SRModel(_opt([dict(type="l1loss", loss_weight=1.0), dict(type="charbonnierloss", loss_weight=-0.5)], blocks=1))
+    hp = OE.esrgan_hparams(scale=4, num_blocks=1)
+    sd = OE.init_state_dict(hp, 2)
+    model.net_g.load_state_dict(sd)
+    lq, gt = _data(seed=13, n=2, s=12)
+    lq_up = torch.nn.functional.interpolate(lq, scale_factor=4, mode="bicubic", antialias=True).clamp(0, 1)
+    params = OrderedDict((k, v.clone().requires_grad_(True)) for k, v in sd.items())
+    out = OE.forward(params, lq, hp)
+    l1, lc = OL.l1(out, gt), OL.charbonnier(out, lq_up)
+    total = l1 + 0.5 * lc
+    grads = torch.autograd.grad(total, list(params.values()))
+    model.feed_data({"lq": lq, "gt": gt})
+    model.optimize_parameters(1, 0, True)
+    log = model.get_current_log()
+    for k, ref in (("l_g_l1", l1), ("l_g_charbonnier", 0.5 * lc), ("l_g_total", total)):
+        assert abs(log[k] - float(ref)) < 2e-5 * abs(float(ref)), (k, log[k], float(ref))
+    og = model.optimizers[0]
+    e = max(rel_l2(og.state[p]["exp_avg"].cpu(), 0.1 * g) for p, g in zip(model.net_g.parameters(), grads))
+    assert e < 1e-4, e
+    assert abs(float(lc) - float(OL.charbonnier(out, gt))) > 1e-3          # the two targets really differ

@@ -363,10 +363,19 @@ class SRModel:
         if self.scaler_g.enabled and not hip_net:
             raise NotImplementedError("fp16 + loss scaling is built for the HIP generators only; use amp_bf16: true with foreign modules")
 
+        lq_target = None
         for label, loss in self.losses.items():
             w = abs(loss.loss_weight)
+            target = gt
             if loss.loss_weight < 0:
-                raise NotImplementedError("negative loss_weight (bicubic-LQ target, sr_model.py:503-516) is not on the HIP path yet")
+                # sr_model.py:503-516: a negative weight selects the bicubic-upsampled LQ as the target of that loss (its magnitude is the weight):
+                # clamp(F.interpolate(lq, scale_factor=scale, mode="bicubic", antialias=True), 0, 1) -- the separable gather of the OTF resize
+                # (tr_resample_axis over ATen's antialias tables, data/otf.py) computes exactly that
+                if lq_target is None:
+                    from ..data.otf import resize_pt
+
+                    lq_target = resize_pt(self.lq.float(), "bicubic", size=(self.lq.shape[2] * self.opt.scale, self.lq.shape[3] * self.opt.scale)).contiguous()
+                target = lq_target
             slot = len(keys)
             if label == "l_g_gan" and hasattr(loss, "hip_value_and_grad") and hasattr(self.net_d, "forward_hip"):
                 # generator-side GAN term, all on HIP: D(output) -> loss(pred, real) -> dL/dlogits -> D backward to the image only
@@ -381,7 +390,7 @@ class SRModel:
                 # fused head.  scalar head: total += loss*w/acc ; dict head: total += v*w*acc  (sr_model.py:654-663)
                 is_dict = getattr(loss, "returns_dict", False)
                 k = float(acc) if is_dict else 1.0 / acc
-                subs = loss.hip_value_and_grad(self.output, gt, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
+                subs = loss.hip_value_and_grad(self.output, target, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
                                                grad_weight=w * k * S, grad=gout, first=first)
                 keys += [f"{label}_{sub}" for sub in subs] if subs else [label]
                 first = False
@@ -394,7 +403,7 @@ class SRModel:
                         assert self.net_d is not None
                         val = loss(self.net_d(out_leaf), True, is_disc=False)
                     else:
-                        val = loss(out_leaf, gt)
+                        val = loss(out_leaf, target)
                 items = [(f"{label}_{sub}", v, float(acc)) for sub, v in val.items()] if isinstance(val, dict) else [(label, val, 1.0 / acc)]
                 for key, v, k in items:
                     wv = v * w
