@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 2   /* 2: tr_tune_set / tr_tune_get; tr_adamw_ema skips the update on the device when *grad_norm is not finite */
+#define TR_ABI_VERSION 3   /* 3: tr_batchnorm_fwd / _bwd; 2: tr_tune_set / tr_tune_get; tr_adamw_ema skips the update on the device when *grad_norm is not finite */
 
 enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2, TR_BF16X3 = 3 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
@@ -339,6 +339,19 @@ int    tr_window_attention_bwd(void* stream, const tr_window_attn_desc* d);
 /* nn.PixelShuffle(r) on NHWC views (:714-717): out[n, y*r+dy, x*r+dx, ch] = in[n, y, x, ch*r*r + dy*r + dx]; inverse != 0 is
  * pixel_unshuffle (its adjoint).  n, h, w are the LOW-resolution dims, c the high-resolution channel count. */
 int tr_pixel_shuffle(void* stream, tr_view in, tr_view out, int n, int h, int w, int c, int r, int inverse);
+
+/* ---- nn.BatchNorm2d(affine=True) + activation on NHWC views (VGGStyleDiscriminator: conv -> BatchNorm2d -> LeakyReLU(0.2), discriminator_arch.py:31-57,70-92)
+ * training != 0: per-channel statistics of THIS batch over the npix = N*H*W pixel records (biased variance normalises; running_mean / running_var, if given,
+ *   move by `momentum` towards the batch mean / UNBIASED variance, torch's rule); save_mean / save_rstd (c floats each) keep what backward needs;
+ * training == 0: the running statistics normalise.  y = act(gamma * (x - mean) * rstd + beta), act in {TR_ACT_NONE, TR_ACT_LRELU, TR_ACT_RELU}.
+ * Backward: gy is the gradient at y; with y given, the activation's derivative is taken from its sign (slope for y <= 0).  dx, and dgamma / dbeta
+ * (+)= when accumulate != 0.  Reductions run in a fixed order (double-precision fold of per-block fp32 partials): reproducible bit for bit.
+ * workspace: tr_batchnorm_workspace_bytes(c) bytes, 16-byte aligned; c a multiple of 4. */
+size_t tr_batchnorm_workspace_bytes(int c);
+int tr_batchnorm_fwd(void* stream, tr_view x, tr_view y, int64_t npix, int c, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     float momentum, float eps, int training, int act, float slope, float* save_mean, float* save_rstd, void* workspace, size_t workspace_bytes);
+int tr_batchnorm_bwd(void* stream, tr_view gy, tr_view x, tr_view y, tr_view dx, int64_t npix, int c, const float* gamma, const float* save_mean,
+                     const float* save_rstd, float slope, float* dgamma, float* dbeta, int accumulate, void* workspace, size_t workspace_bytes);
 
 /* ---- optimizer sweep --------------------------------------------------------------------------
  * torch.optim.AdamW (optimizers/__init__.py:30-47, templates: lr 2e-4, betas (0.9, 0.99), wd 0)

@@ -29,6 +29,8 @@ Fixtures
                    its gate forced open: input, drawn parameters (replayed from the same seed in the reference's draw order), output; and one
                    run with the gate closed (pass-through, one draw consumed).
   psnr.pt          metrics/psnr_ssim.py: calculate_psnr (numpy, 8-bit images, RGB and Y) and calculate_psnr_pt (RGB and Y, crop 0 / 4).
+  vgg_style_discriminator.pt   archs/discriminator_arch.py:9-95 VGGStyleDiscriminator (num_feat 8, input 128, batch 2): state dict, training-mode logits, input and
+                   parameter gradients, BatchNorm running statistics after the forward, eval-mode logits.
 """
 import importlib.util
 import math
@@ -383,8 +385,40 @@ def psnr():
     print("psnr.pt:", fix["pt"], fix["np"])
 
 
+def vgg_style_discriminator():
+    """archs/discriminator_arch.py:9-95 (torch only): training-mode forward of a seeded batch (batch statistics, running statistics updated once),
+    input and parameter gradients for a fixed cotangent, then the eval-mode output on the updated running statistics."""
+    D = _load("traiNNer.archs.discriminator_arch", "traiNNer/archs/discriminator_arch.py")
+    fix = {}
+    for tag, kw, nb in (("nf8_128", dict(num_in_ch=3, num_feat=8, input_size=128), 2),):
+        torch.manual_seed(77)
+        net = D.VGGStyleDiscriminator(**kw).train()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():            # non-trivial affine parameters and running statistics
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.add_(0.2 * torch.randn(m.weight.shape, generator=g))
+                    m.bias.add_(0.1 * torch.randn(m.bias.shape, generator=g))
+                    m.running_mean.add_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                    m.running_var.mul_(1.0 + 0.2 * torch.rand(m.running_var.shape, generator=g))
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        x = torch.rand(nb, 3, kw["input_size"], kw["input_size"], generator=g).requires_grad_(True)
+        out = net(x)
+        cot = torch.randn(out.shape, generator=g)
+        grads = torch.autograd.grad(out, [x, *net.parameters()], cot)
+        names = [k for k, _ in net.named_parameters()]
+        after = {k: v.clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k}
+        net.eval()
+        with torch.no_grad():
+            out_eval = net(x.detach())
+        fix[tag] = dict(kwargs=kw, state=state, x=x.detach(), out=out.detach(), cotangent=cot, gx=grads[0], grads=dict(zip(names, grads[1:])), after=after,
+                        out_eval=out_eval, n_params=sum(p.numel() for p in net.parameters()))
+    torch.save(fix, os.path.join(OUT, "vgg_style_discriminator.pt"))
+    print("vgg_style_discriminator.pt:", {k: (tuple(v["out"].shape), v["n_params"]) for k, v in fix.items()})
+
+
 if __name__ == "__main__":
     setup()
-    which = sys.argv[1:] or ["esrgan", "swin", "otf", "psnr"]
+    which = sys.argv[1:] or ["esrgan", "swin", "otf", "psnr", "vggd"]
     for w in which:
-        {"esrgan": esrgan_twin, "swin": swin_twin, "otf": paragon_otf, "psnr": psnr}[w]()
+        {"esrgan": esrgan_twin, "swin": swin_twin, "otf": paragon_otf, "psnr": psnr, "vggd": vgg_style_discriminator}[w]()

@@ -126,3 +126,66 @@ def test_unet_discriminator_matches_reference_golden(cuda, compute):
         xi = x.clone().requires_grad_(True)
         net(xi).mean().backward()
         assert xi.grad is not None and torch.isfinite(xi.grad).all() and xi.grad.abs().sum() > 0
+
+
+def test_vgg_style_discriminator_matches_reference_module(cuda):
+    """`vggstylediscriminator` on HIP against the REFERENCE MODULE's own tensors (tests/golden/vgg_style_discriminator.pt, made by
+    tests/golden/make_golden_twins.py from archs/discriminator_arch.py:9-95 loaded by path): training-mode logits (BatchNorm on batch statistics),
+    input gradient and every parameter gradient, running statistics after the forward, eval-mode logits on the updated statistics.  fp32 compute;
+    ten conv + BatchNorm stages deep, so the bound is the fp32-network bound of the other archs (1e-5 forward, 2e-4 gradients)."""
+    import os
+
+    from trainner_redux_amd.archs import build_network
+
+    e = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vgg_style_discriminator.pt"), weights_only=True)["nf8_128"]
+    net = build_network({"type": "vggstylediscriminator", **e["kwargs"]})
+    assert sum(p.numel() for p in net.parameters()) == e["n_params"]
+    assert list(net.state_dict().keys()) == list(e["state"].keys())
+    net.load_state_dict(e["state"], strict=True)
+    net = net.to(cuda).train()
+    net.compute_dtype = torch.float32
+    out = net.forward_hip(e["x"].to(cuda), train=True)
+    e_out = rel_l2(out.cpu(), e["out"])
+    assert out.shape == e["out"].shape and e_out < 1e-5, e_out
+    gx = torch.zeros_like(e["x"]).to(cuda)
+    net.backward_hip(e["cotangent"].to(cuda), param_grads=True, input_grad=gx, input_grad_accumulate=False)
+    e_gx = rel_l2(gx.cpu(), e["gx"])
+    errs = {k: rel_l2(p.grad.cpu(), e["grads"][k]) for k, p in net.named_parameters()}
+    worst = max(errs, key=errs.get)
+    print(f"VGGStyleDiscriminator vs reference module: logits {e_out:.2e}, input gradient {e_gx:.2e}, worst parameter gradient {worst} {errs[worst]:.2e}")
+    assert e_gx < 2e-4 and errs[worst] < 2e-4, (e_gx, worst, errs[worst])
+    sd = net.state_dict()
+    for k, v in e["after"].items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v), k
+        else:
+            assert rel_l2(sd[k].cpu(), v) < 1e-5, k
+    net.eval()
+    with torch.no_grad():
+        oe = net(e["x"].to(cuda))
+    assert rel_l2(oe.cpu(), e["out_eval"]) < 1e-5
+    # the autograd bridge (what a stock GAN loss on top of it uses)
+    net.train()
+    xr = e["x"].to(cuda).requires_grad_(True)
+    net(xr).backward(e["cotangent"].to(cuda))
+    assert rel_l2(xr.grad.cpu(), e["gx"]) < 2e-4
+
+
+def test_vgg_style_discriminator_trains_in_the_gan_step(cuda):
+    """network_d: vggstylediscriminator through SRModel.optimize_parameters (bf16 AMP): G-side GAN term, D update, finite logs, both nets move."""
+    from tests.test_sr_model_gpu import _opt
+    from trainner_redux_amd.models import SRModel
+
+    model = SRModel(_opt([dict(type="l1loss", loss_weight=1.0), dict(type="ganloss", gan_type="vanilla", loss_weight=0.1)], use_amp=True, blocks=1,
+                         network_d=dict(type="vggstylediscriminator", num_feat=16, input_size=128), optim_d=dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99])))
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(4, 3, 128, 128, generator=g)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    wg0, wd0 = model.net_g.flat_parameters()[0].clone(), model.net_d.flat_parameters()[0].clone()
+    for it in (1, 2):
+        model.feed_data({"lq": lq, "gt": gt})
+        model.optimize_parameters(it, 0, True)
+    log = model.get_current_log()
+    assert {"l_g_l1", "l_g_gan", "l_d_real", "l_d_fake", "grad_norm_g", "grad_norm_d"} <= set(log) and all(v == v and abs(v) < 1e6 for v in log.values()), log
+    assert (model.net_g.flat_parameters()[0] - wg0).abs().max() > 0 and (model.net_d.flat_parameters()[0] - wd0).abs().max() > 0
+    assert int(model.net_d.state_dict()["bn0_1.num_batches_tracked"]) == 6          # three training-mode D forwards per step (sr_model.py:547,757-758)

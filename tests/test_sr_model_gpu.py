@@ -88,6 +88,7 @@ def test_gan_step_matches_oracle(cuda):
     from trainner_redux_amd.models import SRModel
 
     wg = 0.1
+    torch.manual_seed(0)             # the discriminator's initial weights and u / v come from torch's global generator
     model = SRModel(_opt([dict(type="l1loss", loss_weight=1.0), dict(type="ganloss", gan_type="vanilla", loss_weight=wg)],
                          network_d=dict(type="unetdiscriminatorsn", num_in_ch=3, num_feat=16, skip_connection=True),
                          optim_d=dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99]), blocks=1))
@@ -131,8 +132,13 @@ def test_gan_step_matches_oracle(cuda):
     dnow = model.net_d.state_dict()
     e_d = max(rel_l2(dnow[k].cpu(), dp[k].data) for k in dkeys)
     e_uv = max(rel_l2(dnow[k].cpu(), state[k]) for k in dsd if k.endswith(("weight_u", "weight_v")))
-    print("G weights", e_g, "D weights", e_d, "u/v", e_uv)
-    assert e_g < 1e-5 and e_d < 1e-5 and e_uv < 1e-5
+    # the rounding-tight comparison of the D update is its first moment (0.1 x gradient); the weights after a FIRST AdamW step move by lr * g / (|g| + eps),
+    # i.e. by +-lr wherever |g| >> eps: a gradient element at fp32 rounding level can flip its step (seen once in ~10 unseeded runs: 7e-5 on the D weights)
+    od = model.optimizers[1]
+    m_d = {k: od.state[p]["exp_avg"].cpu() for k, p in model.net_d.named_parameters() if p in od.state}
+    e_md = max(rel_l2(m_d[k], ods.m[k]) for k in dkeys if k in m_d)
+    print("G weights", e_g, "D weights", e_d, "D first moments", e_md, "u/v", e_uv)
+    assert e_g < 1e-5 and e_md < 1e-5 and e_d < 5e-4 and e_uv < 1e-5
 
 
 def test_bf16_step_and_foreign_loss_head(cuda):

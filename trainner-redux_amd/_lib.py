@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 F32_WINOGRAD43 = 101    # ... tr_conv3x3_winograd43_f32 (F(4x4, 3x3), weights from tr_pack_winograd43)
@@ -175,6 +175,11 @@ SYMBOLS = {
     "tr_maxpool2x2_bwd": (C.c_int, [C.c_void_p, View, View, View, C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_pixel_loss": (C.c_int, [C.c_void_p, C.POINTER(PixelLossDesc)]),
     "tr_pixel_loss_pool_bwd": (C.c_int, [C.c_void_p, C.POINTER(PixelLossDesc), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tr_batchnorm_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "tr_batchnorm_fwd": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "tr_batchnorm_bwd": (C.c_int, [C.c_void_p, View, View, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_size_t]),
     "tr_sumsq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "tr_adamw_ema": (C.c_int, [C.c_void_p, C.POINTER(AdamWDesc)]),
 }

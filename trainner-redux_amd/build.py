@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libtrainner_hip.so")
 RESOURCES = os.path.join(HERE, "kernel_resources.json")   # per-kernel VGPRs / scratch / occupancy from the compiler (tests assert scratch == 0)
-SOURCES = ["common.hip", "conv3x3.hip", "conv_ring.hip", "pack.hip", "wgrad3x3.hip", "wgrad_ring.hip", "eltwise.hip", "loss.hip", "optim.hip", "stem.hip", "disc.hip", "token.hip", "attn_mfma.hip", "metrics.hip", "gated.hip", "otf.hip", "winograd.hip", "winograd43.hip"]
+SOURCES = ["common.hip", "conv3x3.hip", "conv_ring.hip", "pack.hip", "wgrad3x3.hip", "wgrad_ring.hip", "eltwise.hip", "loss.hip", "optim.hip", "stem.hip", "disc.hip", "token.hip", "attn_mfma.hip", "metrics.hip", "gated.hip", "otf.hip", "winograd.hip", "winograd43.hip", "bnorm.hip"]
 
 
 def _stale() -> bool:

@@ -448,6 +448,25 @@ def spectral_norm_bwd(g_wsn: torch.Tensor, w_sn: torch.Tensor, u, v, sigma, g_wo
                                          g_worig.data_ptr(), rows, cols, scratch(w_sn.device).data_ptr()), "tr_spectral_norm_bwd")
 
 
+def batchnorm_workspace(c: int, device) -> torch.Tensor:
+    return torch.empty(int(L.lib().tr_batchnorm_workspace_bytes(c)) // 8 + 2, dtype=torch.float64, device=device)
+
+
+def batchnorm_fwd(x: L.View, y: L.View, npix: int, c: int, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor | None, running_var: torch.Tensor | None,
+                  save_mean: torch.Tensor | None, save_rstd: torch.Tensor | None, workspace: torch.Tensor, *, training: bool, momentum: float = 0.1, eps: float = 1e-5,
+                  act: int = L.ACT_NONE, slope: float = 0.2):
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    L.check(L.lib().tr_batchnorm_fwd(stream_ptr(), x, y, npix, c, gamma.data_ptr(), beta.data_ptr(), p(running_mean), p(running_var), momentum, eps, 1 if training else 0,
+                                     act, slope, p(save_mean), p(save_rstd), workspace.data_ptr(), workspace.numel() * workspace.element_size()), "tr_batchnorm_fwd")
+
+
+def batchnorm_bwd(gy: L.View, x: L.View, y: L.View, dx: L.View, npix: int, c: int, gamma: torch.Tensor, save_mean: torch.Tensor, save_rstd: torch.Tensor,
+                  dgamma: torch.Tensor | None, dbeta: torch.Tensor | None, workspace: torch.Tensor, *, slope: float = 0.2, accumulate: bool = True):
+    p = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+    L.check(L.lib().tr_batchnorm_bwd(stream_ptr(), gy, x, y, dx, npix, c, gamma.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), slope, p(dgamma), p(dbeta),
+                                     1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size()), "tr_batchnorm_bwd")
+
+
 def gan_loss(gan_type: str, logits: torch.Tensor, target_is_real: bool, is_disc: bool, value_out: torch.Tensor, *, value_weight=1.0,
              total_out=None, total_weight=0.0, grad: torch.Tensor | None = None, grad_weight=1.0, real_label=1.0, fake_label=0.0):
     _need_cuda(logits, value_out, grad, total_out)
