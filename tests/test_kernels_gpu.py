@@ -490,12 +490,26 @@ def test_stem_conv_from_nchw_image(cuda, pad, shape):
     assert torch.all(buf[..., :4] == 7.0) and torch.all(buf[..., 4 + cout:] == 7.0)      # the slice's neighbours are untouched
 
 
+@pytest.mark.parametrize("linear_impl", [0, 1])
 @pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("dims", [(2, 16, 32, 192, 180), (1, 8, 32, 64, 60), (2, 24, 32, 384, 180), (2, 18, 32, 192, 540), (1, 8, 32, 192, 256),
                                   (1, 6, 32, 192, 300), (2, 16, 32, 192, 360), (1, 9, 32, 64, 120), (1, 8, 48, 64, 60), (2, 5, 32, 64, 24)])
-def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
+def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims, linear_impl):
     """nn.Linear over tokens (drct_arch.py:64-66,166-168) = the MFMA kernel with ksize 1 on an n x h x 32 token grid:
-    forward with exact GELU (+ pre-activation side output), input gradient with the GELU-derivative mask, weight/bias gradient."""
+    forward with exact GELU (+ pre-activation side output), input gradient with the GELU-derivative mask, weight/bias gradient.
+    linear_impl 0: the LDS-DMA staged token GEMM (16-bit operands, the default), 1: the register-staged one."""
+    from trainner_redux_amd import _lib as L, ops
+
+    if linear_impl == 1 and compute_name == "f32":
+        pytest.skip("fp32 has one token-GEMM kernel (covered by linear_impl 0)")
+    ops.tune_set("linear_impl", linear_impl)
+    try:
+        _linear_case(cuda, compute_name, dims, linear_impl)
+    finally:
+        ops.tune_set("linear_impl", 0)
+
+
+def _linear_case(cuda, compute_name, dims, linear_impl):
     from trainner_redux_amd import _lib as L, ops
 
     compute, dt, rnd = ct(L, compute_name)
@@ -529,6 +543,9 @@ def test_linear_as_1x1_conv_forward_backward(cuda, compute_name, dims):
     pre_d = torch.zeros(n, h, w, nop, dtype=dt, device=cuda)
     ops.conv3x3(n=n, h=h, w=w, cin=kp, cout=nout, compute=compute, inp=ops.view(xd), out=ops.view(out), out2=ops.view(pre_d), wpacked=slab, bias=bd,
                 act=L.ACT_GELU, ksize=1, sample_scale=keepd)
+    if w == 32 and nout > 32:          # the token-GEMM tiling (64-wide output groups on a 32-wide token grid)
+        want = "linear_dma" if (linear_impl == 0 and compute_name != "f32" and kp >= 64) else "linear"
+        assert ops.last_conv_family() == want, (ops.last_conv_family(), want)
     assert rel_l2(out[..., :nout].reshape(-1, nout).cpu(), y.detach()) < 3e-6
     assert nop == nout or out[..., nout:].abs().max().item() == 0
     tolp = 3e-6 if compute == L.F32 else 3e-3
@@ -634,3 +651,80 @@ def test_winograd43_f32_forward_and_input_gradient(cuda, shape):
         gin = torch.empty(n, h, w, cin, device=cuda)
         ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.F32_WINOGRAD43, inp=ops.view(gyd), out=ops.view(gin), wpacked=Ut, mask=ops.view(md), mask_slope=0.0)
         assert rel_l2(gin.permute(0, 3, 1, 2).cpu(), refg) < 5e-6
+
+
+@pytest.mark.parametrize("linear_impl", [0, 1])
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("dims", [(2, 16, 192, 180), (1, 9, 192, 540), (2, 8, 384, 180), (1, 12, 192, 360), (2, 6, 64, 60), (1, 8, 64, 120)])
+def test_linear_straight_line_epilogue_forms(cuda, compute_name, dims, linear_impl):
+    """The five compile-time epilogue forms of the token GEMM (conv3x3.hip `lin_epilogue_fast`; what SwinIR's Linears use, drct_arch.py:52-75,166-223):
+    plain -> 16-bit, plain -> fp32, bias + keep * v + fp32 residual -> fp32 (+ 16-bit copy), bias + exact GELU -> 16-bit with the pre-activation as second
+    output, GELU-derivative mask -> 16-bit.  Against torch on the CPU and against the generic epilogue (`linear_epilogue` = 1) on the same operands."""
+    from trainner_redux_amd import _lib as L, ops
+
+    compute, dt, rnd = ct(L, compute_name)
+    n, h, kp, nout = dims
+    w = 32
+    k = kp - 12 if kp > 64 else kp - 4
+    nop = (nout + 31) // 32 * 32
+    g = torch.Generator().manual_seed(kp + nout + h)
+    x = rnd(torch.randn(n * h * w, k, generator=g))
+    wt = rnd(torch.randn(nout, k, generator=g) / math.sqrt(k))
+    b = torch.randn(nout, generator=g)
+    keep = torch.tensor([1.25, 0.0][:n])
+    res = torch.randn(n * h * w, nout, generator=g)
+    mk = rnd(torch.randn(n * h * w, nout, generator=g))
+    lin = F.linear(x, wt, b)
+    lin_nb = F.linear(x, wt)
+    kk = keep.repeat_interleave(h * w).view(-1, 1)
+    mref = mk.clone().requires_grad_(True)
+    F.gelu(mref).sum().backward()
+    refs = {"plain_cd": lin, "plain_f32": lin_nb, "res_f32": lin * kk * 1.0 + res, "gelu_cd": F.gelu(lin), "maskg_cd": lin_nb * mref.grad}
+    xd = torch.zeros(n, h, w, kp, dtype=dt, device=cuda)
+    xd[..., :k] = x.view(n, h, w, k).to(cuda, dt)
+    slab = torch.zeros(ops.packed_bytes(kp, nout, compute, 1), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda)
+    plan.add(wt.to(cuda), slab, kp, nout, compute)
+    plan.run()
+    bd, keepd = b.to(cuda), keep.to(cuda)
+    resd = torch.zeros(n, h, w, nop, device=cuda)
+    resd[..., :nout] = res.view(n, h, w, nout).to(cuda)
+    mkd = torch.zeros(n, h, w, nop, dtype=dt, device=cuda)
+    mkd[..., :nout] = mk.view(n, h, w, nout).to(cuda, dt)
+
+    def run(form, generic):
+        out16 = torch.full((n, h, w, nop), 3.0, dtype=dt, device=cuda)
+        out32 = torch.full((n, h, w, nop), 3.0, dtype=torch.float32, device=cuda)
+        o2 = torch.full((n, h, w, nop), 5.0, dtype=dt, device=cuda)
+        K = dict(n=n, h=h, w=w, cin=kp, cout=nout, compute=compute, inp=ops.view(xd), wpacked=slab, ksize=1)
+        with ops.tuned(linear_impl=linear_impl, linear_epilogue=int(generic)):
+            if form == "plain_cd":
+                ops.conv3x3(out=ops.view(out16), bias=bd, **K)
+            elif form == "plain_f32":
+                ops.conv3x3(out=ops.view(out32), **K)
+            elif form == "res_f32":
+                ops.conv3x3(out=ops.view(out32), out2=ops.view(o2), out2_scale=0.5, bias=bd, res1=ops.view(resd), sample_scale=keepd, **K)
+            elif form == "gelu_cd":
+                ops.conv3x3(out=ops.view(out16), out2=ops.view(o2), bias=bd, act=L.ACT_GELU, **K)
+            else:
+                ops.conv3x3(out=ops.view(out16), mask=ops.view(mkd), mask_mode=1, **K)
+        assert ops.last_conv_family() == ("linear_dma" if (linear_impl == 0 and kp >= 64) else "linear")
+        return out16.float().cpu(), out32.cpu(), o2.float().cpu()
+
+    for form, ref in refs.items():
+        f16o, f32o, f2 = run(form, generic=False)
+        g16o, g32o, g2 = run(form, generic=True)
+        ref = ref.detach().view(n, h, w, nout)
+        if form in ("plain_f32", "res_f32"):
+            got, gen = f32o, g32o
+            assert rel_l2(got[..., :nout], ref) < 3e-6, (form, rel_l2(got[..., :nout], ref))
+        else:
+            got, gen = f16o, g16o
+            e = rel_l2(got[..., :nout], rnd(ref))
+            assert e < 1e-3 and (got[..., :nout] == rnd(ref)).float().mean() > 0.98, (form, e)
+        assert torch.equal(got[..., nout:], gen[..., nout:])                 # the padding channels are left alone by both
+        assert rel_l2(got[..., :nout], gen[..., :nout]) < (3e-6 if got is f32o else 1e-3), form
+        if form == "res_f32":
+            assert rel_l2(f2[..., :nout], rnd(ref * 0.5)) < 1e-3 and torch.equal(f2[..., nout:], g2[..., nout:])
+        if form == "gelu_cd":
+            assert rel_l2(f2[..., :nout], rnd(lin.view(n, h, w, nout))) < 1e-3        # the pre-activation the backward's GELU derivative is taken from

@@ -159,3 +159,40 @@ def test_swinir_full_size_step_runs(cuda):
     assert out.shape == (2, 3, 256, 256) and torch.isfinite(out).all()
     net.backward_hip(torch.randn_like(out) / out.numel())
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_swinir_trainer_replays_the_step_as_hip_graphs(cuda, monkeypatch):
+    """SwinIR asks the trainer for hipGraph replay of its step (archs/swinir_arch.py `prefer_hip_graphs`; `use_compile` for the other generators).
+    (a) without DropPath: six steps replayed == six steps launched eagerly, bit for bit; (b) with DropPath (the presets' drop_path_rate 0.1, raised
+    here): the keep masks are drawn on the device INSIDE the captured forward, every replay draws new ones, the backward graph reads the same buffer."""
+    from tests.test_sr_model_gpu import _data, _opt
+    from trainner_redux_amd.models import SRModel
+
+    def run(graphs: bool, dpr: float, steps: int):
+        monkeypatch.setenv("TRAINNER_HIP_GRAPHS", "1" if graphs else "0")
+        torch.manual_seed(5)
+        model = SRModel(_opt([dict(type="l1loss", loss_weight=1.0)], use_amp=True,
+                             network_g=dict(type="swinir_s", depths=[2, 2], num_heads=[6, 6], drop_path_rate=dpr)))
+        assert bool(model.net_g.hip_graphs) == graphs
+        masks, modes = [], []
+        for it in range(1, steps + 1):
+            lq, gt = _data(seed=it, n=2, s=16)
+            model.feed_data({"lq": lq, "gt": gt})
+            model.optimize_parameters(it, 0, True)
+            modes.append((model.net_g._gs or {}).get("mode"))
+            if dpr > 0:
+                masks.append(model.net_g._keep_state["keep"].clone())
+        log = model.get_current_log()
+        return model.net_g.flat_parameters()[0].detach().cpu().clone(), log, masks, modes
+
+    w_g, log_g, _, modes = run(True, 0.0, 6)
+    assert modes[:2] == ["eager", "eager"] and modes[2:] == ["graph"] * 4, modes
+    w_e, log_e, _, modes_e = run(False, 0.0, 6)
+    assert all(m is None for m in modes_e)
+    assert torch.equal(w_g, w_e) and log_g == log_e
+    w_d, log_d, masks, modes = run(True, 0.6, 6)
+    assert modes[2:] == ["graph"] * 4 and torch.isfinite(w_d).all() and all(v == v for v in log_d.values())
+    distinct = {tuple(m.flatten().tolist()) for m in masks[2:]}
+    assert len(distinct) == 4, "every replay must draw fresh DropPath masks"
+    k = masks[-1]
+    assert ((k == 0) | (k >= 1.0)).all() and (k == 0).any() and (k > 0).any()

@@ -11,6 +11,8 @@ B, hw = int(os.environ.get("B", "32")), 64 * 64
 shapes = [(192, 540, "f32out"), (192, 540, "cdout"), (192, 180, "f32out+res"), (192, 360, "gelu"), (384, 180, "f32out+res"), (544, 180, "f32out"), (192, 360, "cdout"),
           (384, 180, "cdout")]
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
+ops.tune_set("linear_impl", 1 if os.environ.get("LINEAR_IMPL") == "reg" else 0)
+ops.tune_set("linear_epilogue", 1 if os.environ.get("LINEAR_EPILOGUE") == "generic" else 0)      # A/B: LDS-DMA staged (default) vs register-staged token GEMM
 cdn, cd, dt = ("f32", L.F32, torch.float32) if "f32" in sys.argv else ("bf16", L.BF16, torch.bfloat16)
 n, h, w = B, hw // 32, 32
 for (cin, cout, mode) in shapes:

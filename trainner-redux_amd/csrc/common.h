@@ -18,7 +18,9 @@ struct Tune {
     int wgrad_impl;       // tr_wgrad3x3: 0 = automatic, 1 = register-staged, 2 = ring whenever eligible
     int wgrad_multi;      // tr_wgrad3x3_multi: 1 = one fused launch per dense block when eligible, 0 = one launch per conv
     int dgrad_image_ref;  // tr_conv3x3_dgrad_image: 1 = per-pixel reference kernel
-    int last_conv_family; // which kernel family served the calling thread's last tr_conv3x3: 1 reg, 2 dma, 3 linear, 4 ring
+    int linear_epilogue;  // token GEMM epilogue: 0 = straight-line forms where they apply, 1 = always the generic epilogue
+    int linear_impl;      // token GEMM (ksize 1 on a 32-wide token grid), 16-bit: 0 = LDS-DMA staged ring, 1 = register-staged one-chunk prefetch
+    int last_conv_family; // which kernel family served the calling thread's last tr_conv3x3: 1 reg, 2 dma, 3 linear, 4 ring, 5 linear (LDS-DMA)
     int last_conv_instance;   // ring: NT*10000 + R*1000 + D*100 + WRES*10 + EPI ; others 0
     int ring_launches;    // number of tr_conv3x3 launches the ring kernel has served since the counter was last set
     long long stamps;     // development builds (-DTR_RING_DEV / -DTR_W43_STAMPS) only: device address for in-kernel time stamps

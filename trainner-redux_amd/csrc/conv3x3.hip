@@ -764,6 +764,117 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
 }
 
 
+// ---- straight-line epilogue of the token GEMM kernels (round 3) ----------------------------------------------------------------------------
+// The generic epilogue above walks a row in a ROLLED loop whose body branches at run time on activation, dtypes, side views and mask mode and, with a
+// residual, waits for one global round trip per 4-channel piece: measured on SwinIR-M's Linears it was 13 - 25 us of a 24 - 34 us launch
+// (tools/bench_linear.py with TRAINNER_CONV_DBG=4: 192 -> 540 24.3 -> 11.1 us, 192 -> 180 + residual 26.1 -> 7.2 us without it).  The five forms SwinIR's
+// forward and backward use get compile-time bodies: all side pieces (bias, residual, mask) of a row are requested back to back, then the row is
+// finished and stored; no run-time dispatch inside.  Semantics as conv_epilogue_impl: bias, [GELU with the pre-activation to out2], per-sample
+// scale, residual, GELU-derivative mask.  Host-checked: cout % 4 == 0, vector-accessible views, w == 32.
+enum { LF_PLAIN_CD = 0, LF_PLAIN_F32 = 1, LF_RES_F32 = 2, LF_GELU_CD = 3, LF_MASKG_CD = 4 };
+
+template <int CT>
+__device__ __forceinline__ uint2 lin_pack4(float a, float b, float c, float d) {
+    if constexpr (CT == TR_BF16) return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+    else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+        const f32x2c u = {a, b}, v = {c, d};
+        return make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(u, h2)), __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2)));
+    }
+}
+template <int CT>
+__device__ __forceinline__ float4 lin_unpack4(uint2 u) {
+    if constexpr (CT == TR_BF16) return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    else return make_float4(tr::f16_to_f32(u.x & 0xffffu), tr::f16_to_f32(u.x >> 16), tr::f16_to_f32(u.y & 0xffffu), tr::f16_to_f32(u.y >> 16));
+}
+
+template <int CT, int NT, int FORM>
+__device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2][NT], char* strip, int nb, int row0, int cbase, int l) {
+    constexpr int CGW = NT * 32, ROWB = CGW * 4 + 16, SEGS = CGW / 4, ITER = 32 * SEGS / 64;
+    const int lr = l & 31, lh = l >> 5;
+    const float ss = a.sample_scale ? a.sample_scale[nb] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = row0 + r;
+        if (oy >= a.h) break;
+        const int64_t tok0 = ((int64_t)nb * a.h + oy) * 32;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *(float4*)(strip + lr * ROWB + (t * 32 + q * 8 + lh * 4) * 4) =
+                    make_float4(acc[r][t][q * 4 + 0], acc[r][t][q * 4 + 1], acc[r][t][q * 4 + 2], acc[r][t][q * 4 + 3]);
+        __builtin_amdgcn_wave_barrier();
+        // side pieces of the whole row first: one memory latency per row
+        float4 b4[ITER];
+        float4 side[(FORM == LF_RES_F32) ? ITER : 1];
+        uint2 mk[(FORM == LF_MASKG_CD) ? ITER : 1];
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int idx = i * 64 + l;
+            const int p = idx / SEGS, seg = idx - p * SEGS;
+            const int co = min(cbase + seg * 4, a.cout - 4);            // clamped: loads stay in range, stores are masked below
+            b4[i] = a.bias ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (FORM == LF_RES_F32) side[i] = *(const float4*)((const float*)a.res1.ptr + (tok0 + p) * a.res1.cstride + a.res1.coff + co);
+            if constexpr (FORM == LF_MASKG_CD) mk[i] = *(const uint2*)((const unsigned short*)a.mask.ptr + (tok0 + p) * a.mask.cstride + a.mask.coff + co);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int idx = i * 64 + l;
+            const int p = idx / SEGS, seg = idx - p * SEGS;
+            const int co = cbase + seg * 4;
+            const float4 raw = *(const float4*)(strip + p * ROWB + seg * 16);
+            float v[4] = {raw.x + b4[i].x, raw.y + b4[i].y, raw.z + b4[i].z, raw.w + b4[i].w};
+            const bool ok = co < a.cout;
+            const int64_t tok = tok0 + p;
+            if constexpr (FORM == LF_GELU_CD) {
+                if (ok) *(uint2*)((unsigned short*)a.out2.ptr + tok * a.out2.cstride + a.out2.coff + co) = lin_pack4<CT>(v[0], v[1], v[2], v[3]);      // pre-activation
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] *= ss;
+            if constexpr (FORM == LF_RES_F32) {
+                v[0] = v[0] * a.scale1 + a.rs1 * side[i].x; v[1] = v[1] * a.scale1 + a.rs1 * side[i].y;
+                v[2] = v[2] * a.scale1 + a.rs1 * side[i].z; v[3] = v[3] * a.scale1 + a.rs1 * side[i].w;
+            }
+            if constexpr (FORM == LF_MASKG_CD) {
+                const float4 m = lin_unpack4<CT>(mk[i]);
+                v[0] *= gelu_grad(m.x); v[1] *= gelu_grad(m.y); v[2] *= gelu_grad(m.z); v[3] *= gelu_grad(m.w);
+            }
+            if (ok) {
+                if constexpr (FORM == LF_PLAIN_F32 || FORM == LF_RES_F32) {
+                    *(float4*)((float*)a.out.ptr + tok * a.out.cstride + a.out.coff + co) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (FORM == LF_RES_F32 && a.out2.ptr) {
+                        const float sc = a.out2_scale;
+                        *(uint2*)((unsigned short*)a.out2.ptr + tok * a.out2.cstride + a.out2.coff + co) = lin_pack4<CT>(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+                    }
+                } else {
+                    *(uint2*)((unsigned short*)a.out.ptr + tok * a.out.cstride + a.out.coff + co) = lin_pack4<CT>(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();       // the strip is rewritten by the next row
+    }
+}
+
+template <int CT, int NT>
+__device__ __forceinline__ void lin_epilogue_fast(const ConvArgs& a, f32x16 (&acc)[2][NT], char* smem, int nb, int row0, int cbase, int wv, int l, bool wave_active) {
+    __syncthreads();                          // every wave is done with the staged operands: LDS is free
+    if (!wave_active || (a.dbg & 4)) return;
+    char* strip = smem + wv * (32 * (NT * 32 * 4 + 16));
+    if constexpr (CT == TR_BF16 || CT == TR_F16) {
+        switch (a.lin_form) {                 // wave-uniform
+            case LF_PLAIN_CD: lin_epi_form<CT, NT, LF_PLAIN_CD>(a, acc, strip, nb, row0, cbase, l); break;
+            case LF_PLAIN_F32: lin_epi_form<CT, NT, LF_PLAIN_F32>(a, acc, strip, nb, row0, cbase, l); break;
+            case LF_RES_F32: lin_epi_form<CT, NT, LF_RES_F32>(a, acc, strip, nb, row0, cbase, l); break;
+            case LF_GELU_CD: lin_epi_form<CT, NT, LF_GELU_CD>(a, acc, strip, nb, row0, cbase, l); break;
+            default: lin_epi_form<CT, NT, LF_MASKG_CD>(a, acc, strip, nb, row0, cbase, l); break;
+        }
+    }
+}
+
 // ---- Linear layers: ksize 1 on a 32-wide token grid, as a GEMM with up to 192 output channels per workgroup ---------------------
 // A 1x1 "conv" has no tap reuse: with the 3x3 tiling (one 64-channel group per workgroup) the token rows are re-read by every
 // output group and the kernel runs at L2 speed (measured 37 TFLOP/s on SwinIR's qkv/proj/fc1/fc2).  Here a workgroup owns
@@ -837,11 +948,132 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(ConvArgs a, int nbl
         if (wave_active && !(a.dbg & 1)) conv_chunk_mfma<CT, NT, R, 1>(hl, wl + wc * (NCG * 32 * 64), acc, wr, lr, lh);
     }
 #undef TR_LIN_ISSUE
-    conv_epilogue<NT, R>(a, acc, smem, nb, y0, 0, cb * 2 + wc, wr, l, wave_active, wv);
+    if ((CT == TR_BF16 || CT == TR_F16) && a.lin_form >= 0) lin_epilogue_fast<CT, NT>(a, acc, smem, nb, y0 + wr * R, (cb * 2 + wc) * NT * 32, wv, l, wave_active);
+    else conv_epilogue<NT, R>(a, acc, smem, nb, y0, 0, cb * 2 + wc, wr, l, wave_active, wv);
+}
+
+// ---- the same GEMM tiling with LDS-DMA staging (round 3) ------------------------------------------------------------------------------
+// linear_kernel above prefetches ONE K-chunk ahead through registers: with K = 192 .. 384 (6 - 12 chunks) a workgroup is a chain of dependent
+// global round trips and every SwinIR Linear took >= 20 us whatever its FLOPs (tools/bench_linear.py: 192 -> 180, 2.3 GFLOP, 25.9 us; 192 -> 540,
+// 6.8 GFLOP, 24.4 us).  Here the operands of chunk ch + 3 go global -> LDS by buffer_load ... lds (no VGPR round trip) into a four-stage ring while
+// chunk ch is multiplied: three chunks (60 KB per workgroup, two workgroups per CU) are in flight, one barrier per chunk, a counted vmcnt wait.
+// The LDS image is position-linear under DMA (lane l of wave-instruction q lands at (q * 64 + l) * 16), so the bank swizzle of the token rows is
+// applied on the SOURCE address; the weight rows are already stored as their LDS image (pack.hip).  Same MFMA chunk routine, same epilogue.
+template <int NP>
+__device__ __forceinline__ void lin_wait_chunks_left(int left) {      // wait until at most `left` newer chunks (NP pieces each) of this wave are outstanding
+    if (left >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (left == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int CT, int NCG, int S>
+__global__ __launch_bounds__(NTHREADS, S <= 2 ? 3 : 2) void linear_dma_kernel(ConvArgs a, int nblk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int R = 2, NT = NCG;
+    constexpr int ES = 2, EPS = 8, CK = 32;                  // 16-bit operands only
+    constexpr int X_BYTES = 128 * 64;
+    constexpr int STAGE = X_BYTES + NCG * 4096;
+    constexpr int P = S - 1;                                 // S ring stages, P chunks requested ahead
+    constexpr int NP = 2 + NCG;                              // DMA pieces per wave and chunk
+    constexpr unsigned OOB = 0x7fffff00u;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int l = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = l & 31, lh = l >> 5;
+    const int wr = wv >> 1, wc = wv & 1;
+
+    const int total = nblk * a.nty * a.n;
+    const int per = (total + 7) >> 3;
+    int t_ = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (t_ >= total) return;
+    const int cb = t_ % nblk; t_ /= nblk;
+    const int y0 = (t_ % a.nty) * 4;
+    const int nb = t_ / a.nty;
+
+    // token rows: piece (q, l) of a chunk = pixel pp = q * 64 + wv * 16 + (l >> 2) (q = 0, 1), stored slot l & 3, source slot swizzled by the pixel
+    const int64_t pixb = (int64_t)a.in.cstride * ES;
+    const unsigned img_bytes = (unsigned)((int64_t)a.h * 32 * pixb);
+    const auto x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.in.ptr + (int64_t)nb * a.h * 32 * pixb), 0, img_bytes, 0x00020000);
+    unsigned xoff[2];
+    int xslot[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int pp = q * 64 + wv * 16 + (l >> 2);
+        const int s = (l & 3) ^ ((pp >> 2) & 3);
+        const bool rowok = (y0 + (pp >> 5)) < a.h;
+        xslot[q] = s;
+        xoff[q] = rowok ? (unsigned)(((int64_t)y0 * 32 + pp) * pixb + (int64_t)(a.in.coff + s * EPS) * ES) : OOB;
+    }
+    const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpacked, 0, (unsigned)((int64_t)a.ncg * a.nchunks * 4096), 0x00020000);
+    unsigned woff[NCG];
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) woff[g] = (cb * NCG + g < a.ncg) ? (unsigned)(((int64_t)(cb * NCG + g) * a.nchunks) * 4096 + wv * 1024 + l * 16) : OOB;
+
+    auto issue = [&](int ch) {
+        char* st = smem + (ch % S) * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool cvalid = (ch * CK + xslot[q] * EPS) < a.cin;      // channel slots past cin read as zero
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (__attribute__((address_space(3))) void*)(st + q * 4096 + wv * 1024), 16, cvalid ? xoff[q] : OOB,
+                                                     ch * 64, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < NCG; ++g)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (__attribute__((address_space(3))) void*)(st + X_BYTES + g * 4096 + wv * 1024), 16, woff[g], ch * 4096,
+                                                     0, 0);
+    };
+
+    f32x16 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+    const bool wave_active = (y0 + wr * R) < a.h;
+    const int nch = a.nchunks;
+    for (int c = 0; c < P && c < nch; ++c) issue(c);
+    for (int ch = 0; ch < nch; ++ch) {
+        // chunk ch has landed once at most min(P - 1, chunks after ch) newer chunks of this wave are outstanding
+        const int newer = nch - 1 - ch;
+        lin_wait_chunks_left<NP>(newer < P - 1 ? newer : P - 1);
+        __syncthreads();                                     // everybody's pieces of chunk ch; every wave has finished reading stage (ch - 1) % S
+        if (ch + P < nch) issue(ch + P);                     // into stage (ch + P) % S == (ch - 1) % S
+        const char* st = smem + (ch % S) * STAGE;
+        if (wave_active) conv_chunk_mfma<CT, NT, R, 1>(st, st + X_BYTES + wc * (NCG * 32 * 64), acc, wr, lr, lh);
+    }
+    if (a.lin_form >= 0) lin_epilogue_fast<CT, NT>(a, acc, smem, nb, y0 + wr * R, (cb * 2 + wc) * NT * 32, wv, l, wave_active);
+    else conv_epilogue<NT, R>(a, acc, smem, nb, y0, 0, cb * 2 + wc, wr, l, wave_active, wv);
+#endif
+}
+
+template <int CT, int NCG, int S>
+int launch_linear_dma(hipStream_t st, const ConvArgs& a, int nblk) {
+    constexpr size_t stage = 128 * 64 + (size_t)NCG * 4096;
+    constexpr size_t strips = (size_t)4 * 32 * (NCG * 32 * 4 + 16);
+    constexpr size_t lds = S * stage > strips ? S * stage : strips;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)linear_dma_kernel<CT, NCG, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int total = nblk * a.nty * a.n;
+    const unsigned grid = (unsigned)(((total + 7) / 8) * 8);
+    tr::tune().last_conv_family = 5;
+    hipLaunchKernelGGL((linear_dma_kernel<CT, NCG, S>), dim3(grid), dim3(NTHREADS), lds, st, a, nblk);
+    return tr::launch_status("tr_conv3x3(linear, LDS-DMA)");
 }
 
 template <int CT, int NCG>
 int launch_linear(hipStream_t st, const ConvArgs& a, int nblk) {
+    if constexpr (CT == TR_BF16 || CT == TR_F16) {
+        // LDS-DMA variant: 16-bit operands, buffer addressing (one sample's token rows and the slab below 2 GiB), 16-byte sliceable input view
+        const bool fits = (int64_t)a.h * 32 * a.in.cstride * 2 < (int64_t)0x7fff0000 && (int64_t)a.ncg * a.nchunks * 4096 < (int64_t)0x7fff0000;
+        // four ring stages, two workgroups per CU.  (Measured and dropped: two stages at three workgroups per CU -- one round of workgroups instead
+        // of 1.5 -- spills the side-input registers of the residual form under the 170-VGPR cap: 192 -> 180 + residual 21.6 -> 51.0 us.)
+        if (tr::tune().linear_impl != 1 && fits && a.nchunks >= 2) return launch_linear_dma<CT, NCG, 4>(st, a, nblk);
+    }
     constexpr size_t stage = 128 * 64 + (size_t)NCG * 4096;
     constexpr size_t strips = (size_t)4 * 32 * (NCG * 32 * 4 + 16);
     constexpr size_t lds = stage > strips ? stage : strips;
@@ -971,8 +1203,20 @@ extern "C" int tr_conv3x3(void* stream, const tr_conv3x3_desc* d) {
 #define TR_BY_CT(FN, ...) (ct == TR_BF16 ? FN<TR_BF16, __VA_ARGS__> : ct == TR_F16 ? FN<TR_F16, __VA_ARGS__> : FN<TR_F32, __VA_ARGS__>)
 #define TR_BY_CT3(FN, ...) (ct == TR_BF16X3 ? FN<TR_BF16X3, __VA_ARGS__> : TR_BY_CT(FN, __VA_ARGS__))
     static const bool no_linear = getenv("TRAINNER_LINEAR") && !strcmp(getenv("TRAINNER_LINEAR"), "conv");
+    a.lin_form = -1;
     if (d->ksize == 1 && a.w == 32 && g.cgw == 64 && d->in_mode == TR_IN_DIRECT && !no_linear) {
         // token grid (Linear layers): GEMM tiling, 128 tokens x up to 192 output channels per workgroup
+        // straight-line epilogue forms (lin_epilogue_fast): 16-bit compute, whole 4-channel pieces, vector-accessible views
+        if ((ct == TR_BF16 || ct == TR_F16) && d->cout % 4 == 0 && a.vec_out && a.vec_out2 && a.vec_res1 && a.vec_mask && !d->res2.ptr &&
+            (!d->bias || ((uintptr_t)d->bias) % 16 == 0) && tr::tune().linear_epilogue != 1) {
+            const bool side = d->res1.ptr || d->mask.ptr;
+            if (!side && d->act == TR_ACT_NONE && !d->out2.ptr) a.lin_form = d->out.dtype == ct ? LF_PLAIN_CD : (d->out.dtype == TR_F32 ? LF_PLAIN_F32 : -1);
+            else if (d->res1.ptr && d->res1.dtype == TR_F32 && !d->mask.ptr && d->act == TR_ACT_NONE && d->out.dtype == TR_F32 && (!d->out2.ptr || d->out2.dtype == ct))
+                a.lin_form = LF_RES_F32;
+            else if (!side && d->act == TR_ACT_GELU && d->out.dtype == ct && d->out2.ptr && d->out2.dtype == ct) a.lin_form = LF_GELU_CD;
+            else if (d->mask.ptr && d->mask_mode == 1 && d->mask.dtype == ct && !d->res1.ptr && d->act == TR_ACT_NONE && d->out.dtype == ct && !d->out2.ptr)
+                a.lin_form = LF_MASKG_CD;
+        }
         const int ncgb = g.ncg == 4 ? 2 : (g.ncg < 3 ? g.ncg : 3);
         const int nblk = (g.ncg + ncgb - 1) / ncgb;
         a.nty = (a.h + 3) / 4;

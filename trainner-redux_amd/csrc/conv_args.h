@@ -18,6 +18,7 @@ struct ConvArgs {
     int ntx, nty, nchunks, ncg;
     int vec_out, vec_out2, vec_res1, vec_res2, vec_mask;
     int ring_mb;         // conv_ring.hip, pipelined mask instances: number of LDS mask-tile buffers (1 or 2)
+    int lin_form;        // token GEMM kernels: straight-line epilogue form (-1: the generic epilogue), conv3x3.hip lin_epilogue_fast
     long long* stamps;   // diagnostics only (TRAINNER_RING_STAMPS = device address): s_memtime stamps of workgroup phases, conv_ring.hip
     int dbg;   // timing experiments only (TRAINNER_CONV_DBG): 1 = skip MFMAs, 2 = skip global loads, 4 = skip epilogue stores, 8 = row-at-a-time epilogue
 };

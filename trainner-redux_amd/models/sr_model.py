@@ -109,9 +109,11 @@ class SRModel:
         self.net_g = build_network({**opt.network_g, "scale": opt.scale}).to(self.device)
         if hasattr(self.net_g, "compute_dtype"):
             self.net_g.compute_dtype = self.compute_dtype
-        if getattr(opt, "use_compile", False) and hasattr(self.net_g, "hip_graphs"):
+        if hasattr(self.net_g, "hip_graphs") and os.environ.get("TRAINNER_HIP_GRAPHS") != "0" and \
+                (getattr(opt, "use_compile", False) or getattr(self.net_g, "prefer_hip_graphs", False)):
             # the reference's `use_compile` (torch.compile around the networks, base_model.py:214-226: spend warm-up time, run steps faster)
-            # maps onto hipGraph replay of the generator's forward / backward launches -- there is no tracing compiler on this path
+            # maps onto hipGraph replay of the generator's forward / backward launches -- there is no tracing compiler on this path.  Generators whose
+            # training step is launch- / latency-bound at training tile sizes (SwinIR: ~1,900 launches of ~15 us) ask for it themselves.
             self.net_g.hip_graphs = True
         self.net_d: nn.Module | None = None
         self.net_g_ema: EMA | None = None

@@ -87,7 +87,7 @@ class tuned:
         return False
 
 
-CONV_FAMILIES = {0: "none", 1: "reg", 2: "dma", 3: "linear", 4: "ring"}
+CONV_FAMILIES = {0: "none", 1: "reg", 2: "dma", 3: "linear", 4: "ring", 5: "linear_dma"}
 
 
 def last_conv_family() -> str:
