@@ -55,6 +55,8 @@ def check():
 def bench():
     shapes = [(16, 256, 256, 64, 32), (16, 256, 256, 96, 32), (16, 256, 256, 128, 32), (16, 256, 256, 160, 32), (16, 256, 256, 192, 64),
               (16, 1024, 1024, 64, 64), (16, 512, 512, 64, 64)]
+    if os.environ.get("SHAPES"):  # e.g. SHAPES=8x64x64x64x32,8x64x64x192x64
+        shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["SHAPES"].split(",")]
     for (n, h, w, cin, cout) in shapes:
         bufs = mk(n, h, w, cin, cout, torch.bfloat16)
         flops = 2.0 * n * h * w * 9 * cin * cout
@@ -83,15 +85,18 @@ def multi():
     """The five weight gradients of a dense block (channel prefixes of one 192-channel x buffer, slices of one 192-channel gradient buffer):
     one fused launch (tr_wgrad3x3_multi) against five separate ones -- agreement, then time per block."""
     nf, gc = 64, 32
-    for (n, h, w) in [(2, 40, 72), (16, 256, 256)]:
+    geoms = [(2, 40, 72), (16, 256, 256)]
+    if os.environ.get("GEOMS"):   # e.g. GEOMS=8x64x64,2x64x64
+        geoms = [tuple(int(v) for v in sh.split("x")) for sh in os.environ["GEOMS"].split(",")]
+    for (n, h, w) in geoms:
         xb = torch.randn(n, h, w, nf + 4 * gc, device=dev).bfloat16()
         g = (torch.randn(n, h, w, nf + 4 * gc, device=dev) / 16).bfloat16()
         shapes = [(nf + gc * (c - 1), gc if c < 5 else nf, 0 if c == 5 else nf + gc * (4 - c)) for c in range(1, 6)]
         need = max(ops.wgrad_workspace_bytes(n, h, w, ci, co) for ci, co, _ in shapes)
         wss = [torch.empty(need // 4 + 16, dtype=torch.float32, device=dev) for _ in range(5)]
 
-        def run(fused):
-            ops.tune_set("wgrad_impl", 2)
+        def run(fused, impl=2):
+            ops.tune_set("wgrad_impl", impl)
             ops.tune_set("wgrad_multi", 1 if fused else 0)
             dws = [torch.full((co, ci, 3, 3), 0.5, device=dev) for ci, co, _ in shapes]
             dbs = [torch.full((co,), 0.25, device=dev) for ci, co, _ in shapes]
@@ -108,9 +113,9 @@ def multi():
             bad += not (ew < 2e-6 and eb < 2e-6)
             print(f"n{n} {h}x{w} conv{k + 1} {shapes[k][0]}->{shapes[k][1]}: dw rel {ew:.2e} db rel {eb:.2e}")
         print("multi check mismatches:", bad)
-        if n * h * w < 256 * 512: continue
-        for name, fused in (("separate", False), ("fused", True)):
-            _, _, f = run(fused)
+        if n * h * w < 256 * 512 and not os.environ.get("GEOMS"): continue
+        for name, fused, impl in (("register-staged, separate", False, 1), ("ring, separate", False, 2), ("ring, fused", True, 2)):
+            _, _, f = run(fused, impl)
             for _ in range(2): f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

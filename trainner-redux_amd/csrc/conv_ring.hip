@@ -902,7 +902,12 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     const int cfg_env = tn.ring_cfg;
     const bool bf = d->compute == TR_BF16;
     const int64_t npix = (int64_t)a.n * a.h * a.w;
-    if (!force && npix < 256 * 512) return -1;                       // fewer than ~one 16 x 32 tile per CU: the register-staged kernel's smaller tiles fill the chip better
+    // No size threshold any more (round 3): measured with tools/ab_ring.py, the ring kernel is ahead of the register-staged one at EVERY size down to a
+    // single 16 x 16 tile (8 x 64 x 64 pixels, the per-GPU batch of BASELINE configs[2]: 64 -> 32 7 vs 14 us, 160 -> 32 9 vs 21 us, 192 -> 64 21 vs 25 us;
+    // one 16 x 16 tile: 7 vs 11 us) -- its straight-line epilogue and DMA staging have the shorter single-tile latency as well.  `conv_impl` 1 selects the
+    // register-staged kernels (A/B, and the cross-check of tests/test_hotpath_gpu.py).
+    (void)npix;
+    (void)force;
     a.ntx = (a.w + TW - 1) / TW;
 #define TR_RING_LAUNCH(NT, R, NCW, NLW, WGS, D, WRES, PIPE)                                                             \
     {                                                                                                                   \

@@ -377,7 +377,8 @@ int wgrad3x3_ring_multi(hipStream_t st, const tr_wgrad3x3_desc* descs, int ndesc
     const tr_wgrad3x3_desc& d0 = descs[0];
     if (d0.ksize != 3 || (d0.compute != TR_BF16 && d0.compute != TR_F16) || d0.in_mode != TR_IN_DIRECT) return -1;
     if ((int64_t)d0.h * d0.w * d0.in.cstride * 2 >= (int64_t)0x7fff0000 || (int64_t)d0.h * d0.w * d0.gy.cstride * 2 >= (int64_t)0x7fff0000) return -1;
-    if ((int64_t)d0.n * d0.h * d0.w < 256 * 512 && impl != 2) return -1;
+    // no size threshold (round 3): the fused dense-block launch beats five separate weight gradients at every size measured (tools/ab_wgrad.py multi:
+    // 8 x 64 x 64 pixels 0.048 vs 0.116 ms per block, 2 x 64 x 64 0.045 vs 0.064, 1 x 24 x 40 0.033 vs 0.054)
     // 32-wide output units (conv, 64-channel input block, group), paired up per input block into 64-wide roles: an x tile staged in LDS serves two
     struct Unit { int k, pc, cg; };
     Unit units[3][2 * TR_WG_MAX_ROLES];
