@@ -14,11 +14,12 @@ form = sys.argv[6] if len(sys.argv) > 6 else "lrelu"
 cfg = int(sys.argv[7]) if len(sys.argv) > 7 else 10
 bufs = AB.mk_bufs(n, h, w, cin, cout, torch.bfloat16, L.BF16)
 _, _, f = AB.run("ring", cfg, n, h, w, cin, cout, form, bufs=bufs)
+ops.tune_set("conv_impl", 2); ops.tune_set("ring_cfg", cfg)
 for _ in range(3): f()
 st = torch.zeros(1024 * 2 * 256, dtype=torch.int64, device=dev)   # the kernel stamps workgroups below 1024 only
-os.environ["TRAINNER_RING_STAMPS"] = hex(st.data_ptr())
+ops.tune_set("stamps", st.data_ptr())          # honoured by builds with -DTR_RING_DEV only (TRAINNER_DEV_BUILD=1 python trainner-redux_amd/build.py --force)
 f(); torch.cuda.synchronize()
-os.environ.pop("TRAINNER_RING_STAMPS")
+ops.tune_set("stamps", 0)
 s = st.cpu().numpy().reshape(1024, 2, 256)[:256]
 nchunks = cin // 32
 for b in (0, 100, 255):

@@ -939,6 +939,10 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
         }
         TR_RING_LAUNCH(1, 4, 4, 4, 1, 1, false, false)
     } else {
+        // 64-wide groups: streamed weights, 16-row tiles.  (Round 3, measured and not kept: with K = 64 -- the 64 -> 64 convs of the upsampling tail -- both
+        // weight chunks (74 KB) resident and the ring carrying halo bytes only: same time, 2.24 vs 2.24 ms at 16 x 1024^2.  In-kernel stamps of that launch
+        // (tools/ring_stamps.py, 37k cycles per tile): MFMAs 11.2k, the eight epilogue units of a wave 10.2k (store-issue bound: 64-byte pieces of 128-byte
+        // pixel records), waits for the one-chunk-ahead halo 7-10k.)
         TR_RING_LAUNCH(2, 4, 4, 4, 1, 1, false, false)
     }
 #undef TR_RING_LAUNCH
