@@ -29,6 +29,8 @@ Fixtures
                    its gate forced open: input, drawn parameters (replayed from the same seed in the reference's draw order), output; and one
                    run with the gate closed (pass-through, one draw consumed).
   psnr.pt          metrics/psnr_ssim.py: calculate_psnr (numpy, 8-bit images, RGB and Y) and calculate_psnr_pt (RGB and Y, crop 0 / 4).
+  iterative_schedule.pt   losses/iterative_loss_wrapper.py:87-246: weight / is_active of eight schedules on iterations 0..44, the wrapper's forward on a scalar
+                   and a dict-valued toy module at four iterations, the two constructor rejections.
   vgg_style_discriminator.pt   archs/discriminator_arch.py:9-95 VGGStyleDiscriminator (num_feat 8, input 128, batch 2): state dict, training-mode logits, input and
                    parameter gradients, BatchNorm running statistics after the forward, eval-mode logits.
 """
@@ -417,8 +419,52 @@ def vgg_style_discriminator():
     print("vgg_style_discriminator.pt:", {k: (tuple(v["out"].shape), v["n_params"]) for k, v in fix.items()})
 
 
+def iterative_schedule():
+    """losses/iterative_loss_wrapper.py (torch only): the weight of every schedule shape on a grid of iterations, and the wrapper's forward on
+    a scalar and on a dict-valued toy module (values only -- the toy modules are this script's)."""
+    import warnings
+
+    W = _load("traiNNer.losses.iterative_loss_wrapper", "traiNNer/losses/iterative_loss_wrapper.py")
+
+    class Scalar(nn.Module):
+        def forward(self, a, b):
+            return (a - b).abs().mean()
+
+    class Pair(nn.Module):
+        def forward(self, a, b):
+            return {"p": (a - b).abs().mean(), "q": ((a - b) ** 2).mean()}
+
+    cfgs = [dict(loss_weight=1.0), dict(loss_weight=0.5, start_iter=10), dict(loss_weight=0.0, start_iter=5, target_iter=25, target_weight=2.0),
+            dict(loss_weight=1.0, start_iter=0, target_iter=40, target_weight=0.1, schedule_type="cosine"),
+            dict(loss_weight=0.2, start_iter=8, target_iter=16, target_weight=0.9, schedule_type="step", disable_after=30),
+            dict(loss_weight=0.3, start_iter=0, target_iter=10, target_weight=0.6, disable_after=12, schedule_type="LINEAR"),
+            dict(loss_weight=0.3, start_iter=2, target_iter=10, target_weight=0.6, schedule_type="nonsense"),
+            dict(loss_weight=0.7, start_iter=3, target_iter=3, target_weight=1.5)]
+    iters = list(range(0, 45))
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(2, 3, 8, 8, generator=g), torch.rand(2, 3, 8, 8, generator=g)
+    rows = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in cfgs:
+            w = W.create_iterative_loss(Scalar(), c)
+            wp = W.create_iterative_loss(Pair(), c)
+            rows.append(dict(cfg=c, weights=[float(w.get_current_weight(i)) for i in iters], active=[bool(w.is_active(i)) for i in iters],
+                             scalar=[float(w(a, b, current_iter=i)) for i in (0, 9, 20, 44)],
+                             pair=[{k: float(v) for k, v in wp(a, b, current_iter=i).items()} for i in (0, 9, 20, 44)], info=w.get_schedule_info()))
+    bad = []
+    for kw in (dict(loss_weight=1.0, start_iter=10, target_iter=5), dict(loss_weight=1.0, target_weight=-0.5)):
+        try:
+            W.create_iterative_loss(Scalar(), kw)
+            bad.append(None)
+        except ValueError as e:
+            bad.append(str(e))
+    torch.save(dict(iters=iters, fwd_iters=[0, 9, 20, 44], a=a, b=b, rows=rows, rejected=bad), os.path.join(OUT, "iterative_schedule.pt"))
+    print("iterative_schedule.pt:", len(rows), "schedules;", bad)
+
+
 if __name__ == "__main__":
     setup()
-    which = sys.argv[1:] or ["esrgan", "swin", "otf", "psnr", "vggd"]
+    which = sys.argv[1:] or ["esrgan", "swin", "otf", "psnr", "vggd", "sched"]
     for w in which:
-        {"esrgan": esrgan_twin, "swin": swin_twin, "otf": paragon_otf, "psnr": psnr, "vggd": vgg_style_discriminator}[w]()
+        {"esrgan": esrgan_twin, "swin": swin_twin, "otf": paragon_otf, "psnr": psnr, "vggd": vgg_style_discriminator, "sched": iterative_schedule}[w]()

@@ -328,3 +328,54 @@ def test_update_learning_rate_warmup_ramp_and_skipped_step_gating():
     for it in range(1, 8):
         SRModel.update_learning_rate(me2, it)
     assert abs(me2.optimizers[0].param_groups[0]["lr"] - 2e-4 * 0.25) < 1e-12            # two milestones (3, 6) passed after 7 steps
+
+
+def test_iterative_loss_wrapper_matches_reference_golden():
+    """tests/golden/iterative_schedule.pt (make_golden_twins.py `sched`, from the reference's losses/iterative_loss_wrapper.py): schedule weights on
+    iterations 0..44 for eight schedules, `is_active`, the tensor form on scalar / dict-valued modules, the constructor's rejections; and `build_loss`
+    splitting the schedule keys off the loss options (losses/__init__.py:79-110)."""
+    import warnings
+
+    from torch import nn
+
+    from trainner_redux_amd.losses import build_loss
+    from trainner_redux_amd.losses.iterative_loss_wrapper import IterativeLossWrapper, create_iterative_loss
+
+    fix = torch.load(os.path.join(GOLD, "iterative_schedule.pt"), weights_only=True)
+
+    class Scalar(nn.Module):
+        def forward(self, a, b):
+            return (a - b).abs().mean()
+
+    class Pair(nn.Module):
+        returns_dict = True
+
+        def forward(self, a, b):
+            return {"p": (a - b).abs().mean(), "q": ((a - b) ** 2).mean()}
+
+    a, b = fix["a"], fix["b"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for row in fix["rows"]:
+            w, wp = create_iterative_loss(Scalar(), row["cfg"]), create_iterative_loss(Pair(), row["cfg"])
+            assert [w.get_current_weight(i) for i in fix["iters"]] == row["weights"], row["cfg"]      # same float expressions: exact
+            assert [w.is_active(i) for i in fix["iters"]] == row["active"]
+            assert w.get_schedule_info() == row["info"]
+            assert w.loss_weight == row["cfg"]["loss_weight"] and wp.returns_dict and not w.returns_dict
+            for k, i in enumerate(fix["fwd_iters"]):
+                assert abs(float(w(a, b, current_iter=i)) - row["scalar"][k]) <= 1e-7 * max(1.0, abs(row["scalar"][k]))
+                got = wp(a, b, current_iter=i)
+                assert set(got) == set(row["pair"][k]) and all(abs(float(got[n]) - v) <= 1e-7 for n, v in row["pair"][k].items())
+    for kw, msg in zip((dict(loss_weight=1.0, start_iter=10, target_iter=5), dict(loss_weight=1.0, target_weight=-0.5)), fix["rejected"]):
+        with pytest.raises(ValueError) as e:
+            create_iterative_loss(Scalar(), kw)
+        assert str(e.value) == msg
+    with pytest.raises(ValueError, match="current_iter must be provided"):
+        create_iterative_loss(Scalar(), dict(loss_weight=1.0))(a, b)
+    with pytest.warns(UserWarning, match="very small effective weight"):
+        create_iterative_loss(Scalar(), dict(loss_weight=1.0, start_iter=5)).step_weight(0)
+
+    wrapped = build_loss({"type": "l1loss", "loss_weight": 0.5, "start_iter": 4, "target_iter": 8, "target_weight": 1.0, "loss_decay": 0.1})
+    assert isinstance(wrapped, IterativeLossWrapper) and type(wrapped.loss_module).__name__ == "L1Loss"
+    assert wrapped.loss_weight == 0.5 and wrapped.get_current_weight(6) == 0.75 and wrapped.get_current_weight(3) == 0.0
+    assert not isinstance(build_loss({"type": "l1loss", "loss_weight": 0.5}), IterativeLossWrapper)

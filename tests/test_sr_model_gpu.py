@@ -141,6 +141,76 @@ def test_gan_step_matches_oracle(cuda):
     assert e_g < 1e-5 and e_md < 1e-5 and e_d < 5e-4 and e_uv < 1e-5
 
 
+def _gan_model(losses, seed=0, adaptive_d=False):
+    from oracle import esrgan as OE
+    from trainner_redux_amd.models import SRModel
+
+    torch.manual_seed(seed)
+    opt = _opt(losses, network_d=dict(type="unetdiscriminatorsn", num_in_ch=3, num_feat=16, skip_connection=True),
+               optim_d=dict(type="AdamW", lr=1e-4, weight_decay=0, betas=[0.9, 0.99]), blocks=1)
+    opt.train.adaptive_d = adaptive_d
+    opt.train.scheduler = dict(type="MultiStepLR", milestones=[50], gamma=0.5)
+    model = SRModel(opt)
+    model.net_g.load_state_dict(OE.init_state_dict(OE.esrgan_hparams(scale=4, num_blocks=1), 3))
+    return model
+
+
+def test_iteration_scheduled_weights_reach_the_heads_like_plain_weights(cuda):
+    """IterativeLossWrapper on the HIP path (losses/__init__.py:79-110, sr_model.py:523-663,763-768): a step at iteration 5 of
+    [L1 0.5 ramping 0.5 -> 1.5 over 10, vanilla GAN 1.0 ramping 1.0 -> 0.2 over 10, MSE not started yet] must equal the step of the plain configuration
+    [L1 0.5 * 1.0, GAN 1.0 * 0.6] -- G side weight = abs(loss_weight) * schedule(iter), D side weight = schedule(iter) -- and the inactive
+    head logs 0 and moves nothing."""
+    sched = [dict(type="l1loss", loss_weight=0.5, start_iter=0, target_iter=10, target_weight=1.5),
+             dict(type="ganloss", gan_type="vanilla", loss_weight=1.0, start_iter=0, target_iter=10, target_weight=0.2, schedule_type="linear"),
+             dict(type="mseloss", loss_weight=1.0, start_iter=100, warn_on_unused=False)]
+    plain = [dict(type="l1loss", loss_weight=0.5), dict(type="ganloss", gan_type="vanilla", loss_weight=0.6)]
+    a, b = _gan_model(sched), _gan_model(plain)
+    assert type(a.losses["l_g_gan"]).__name__ == "IterativeLossWrapper" and a.losses["l_g_gan"].get_current_weight(5) == pytest.approx(0.6)
+    lq, gt = _data(seed=5, n=2, s=8)
+    for m in (a, b):
+        m.feed_data({"lq": lq, "gt": gt})
+        m.optimize_parameters(5, 0, True)
+    la, lb = a.get_current_log(), b.get_current_log()
+    assert la["l_g_mse"] == 0.0 and set(la) - {"l_g_mse"} == set(lb), (set(la), set(lb))
+    for k in lb:
+        assert abs(la[k] - lb[k]) <= 1e-6 * abs(lb[k]), (k, la[k], lb[k])
+    for na, nb in ((a.net_g, b.net_g), (a.net_d, b.net_d)):
+        sa, sb = na.state_dict(), nb.state_dict()
+        e = max(rel_l2(sa[k].float().cpu(), sb[k].float().cpu()) for k in sb)
+        assert e < 1e-6, e
+    # the ramp moves on: at iteration 10 the GAN weight is the target on both sides
+    assert a.losses["l_g_gan"].get_current_weight(10) == pytest.approx(0.2) and a.losses["l_g_l1"].get_current_weight(10) == 1.5
+
+
+def test_adaptive_d_skips_the_discriminator_update_when_the_gan_ema_rises(cuda):
+    """sr_model.py:558-569: ema' = 0.999 ema + 0.001 l_g_gan (value before loss_weight); ema' > 1.02 ema skips the D update of the step.  The EMA
+    starts at 0 (base_model.py:55), so the first step always skips; with a large EMA the update runs."""
+    wg = 0.1
+    m = _gan_model([dict(type="l1loss", loss_weight=1.0), dict(type="ganloss", gan_type="vanilla", loss_weight=wg)], adaptive_d=True)
+    lq, gt = _data(seed=5, n=2, s=8)
+    d0 = {k: v.detach().clone() for k, v in m.net_d.state_dict().items() if not k.endswith(("weight_u", "weight_v"))}
+    m.feed_data({"lq": lq, "gt": gt})
+    m.optimize_parameters(1, 0, True)
+    log = m.get_current_log()
+    assert "l_d_real" not in log and "grad_norm_d" not in log and m.optimizers_skipped == [False, True]
+    l_gan = log["l_g_gan"] / wg
+    assert float(m.l_g_gan_ema) == pytest.approx(0.001 * l_gan, rel=1e-5)
+    now = m.net_d.state_dict()
+    assert all(torch.equal(now[k], v) for k, v in d0.items())
+    m.update_learning_rate(1)
+    assert m.schedulers[1].last_epoch == 0 and m.schedulers[0].last_epoch == 1            # the skipped optimizer's scheduler waits (base_model.py:378)
+
+    m.reset_current_log()
+    m.l_g_gan_ema.fill_(100.0)
+    m.feed_data({"lq": lq, "gt": gt})
+    m.optimize_parameters(2, 0, True)
+    log = m.get_current_log()
+    assert {"l_d_real", "l_d_fake", "grad_norm_d"} <= set(log) and m.optimizers_skipped == [False, False]
+    assert float(m.l_g_gan_ema) == pytest.approx(99.9 + 0.001 * log["l_g_gan"] / wg, rel=1e-6)
+    now = m.net_d.state_dict()
+    assert any(not torch.equal(now[k], v) for k, v in d0.items())
+
+
 def test_bf16_step_and_foreign_loss_head(cuda):
     """bf16 compute (use_amp + amp_bf16) with a stock-PyTorch loss head registered through the open plugin surface."""
     from torch import nn

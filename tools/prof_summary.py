@@ -68,9 +68,20 @@ def mfma_busy(d):
     return "\n".join(out)
 
 
+def pmc_seq(d, counter, pattern):
+    """one line per dispatch, in dispatch order, of the kernels whose name contains `pattern` (per-layer reading of a scripted launch sequence)"""
+    f = (glob.glob(f"{d}/*/*counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"))[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and pattern in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    return "\n".join(f"dispatch {r['Dispatch_Id']:>6s} {short(r['Kernel_Name'])[:60]:60s} {counter}={float(r['Counter_Value']):14.1f} "
+                     f"us={(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:9.1f}" for r in rows)
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    if cmd == "mfma":
+    if cmd == "seq":
+        print(pmc_seq(sys.argv[2], sys.argv[3], sys.argv[4]))
+    elif cmd == "mfma":
         print(mfma_busy(sys.argv[2]))
     elif cmd == "pmcall":
         print(pmc_all(sys.argv[2]))

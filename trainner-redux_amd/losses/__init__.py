@@ -1,8 +1,8 @@
 """`build_loss` -- registry lookup with the reference's call convention
 (/root/reference/traiNNer/losses/__init__.py:42-119): every `*_loss.py` here is imported at package import;
 `build_loss({"type": T, "loss_weight": w, **kw})` -> `LOSS_REGISTRY.get(T)(loss_weight=w, **kw)`.
-Iteration-schedule keys (`start_iter`, `target_iter`, ... :79-110) select the reference's IterativeLossWrapper,
-which is outside the hot path: they are rejected explicitly instead of being ignored.
+Iteration-schedule keys (`start_iter`, `target_iter`, ... :79-110) are split off and the loss is wrapped in `IterativeLossWrapper`
+(iterative_loss_wrapper.py), whose factor SRModel folds into the host-side weights of the HIP head.
 """
 from __future__ import annotations
 
@@ -29,7 +29,10 @@ _SCHEDULE_KEYS = ("start_iter", "target_iter", "target_weight", "disable_after",
 def build_loss(loss_opt: dict[str, Any]) -> nn.Module:
     opt = deepcopy(loss_opt)
     loss_type = opt.pop("type")
-    sched = [k for k in _SCHEDULE_KEYS if k in opt]
+    sched = {k: opt.pop(k) for k in _SCHEDULE_KEYS if k in opt}      # never reach the loss constructor (:92-96)
+    loss = LOSS_REGISTRY.get(loss_type)(**opt)
     if sched:
-        raise NotImplementedError(f"loss schedule keys {sched} (IterativeLossWrapper) are not part of the HIP hot path")
-    return LOSS_REGISTRY.get(loss_type)(**opt)
+        from .iterative_loss_wrapper import create_iterative_loss
+
+        return create_iterative_loss(loss, {**loss_opt, **sched})
+    return loss

@@ -171,8 +171,12 @@ class SRModel:
             self.net_g_ema.initted = self.net_g_ema.initted.cpu()
             if hasattr(self.net_g_ema.ema_model, "compute_dtype"):
                 self.net_g_ema.ema_model.compute_dtype = self.compute_dtype
-        if train_opt.adaptive_d:
-            raise NotImplementedError("adaptive_d (sr_model.py:558-569) is not on the HIP path yet")
+        # adaptive_d (sr_model.py:195-197, 558-569): the D update is skipped on steps where the EMA of the generator-side GAN loss rises by more
+        # than `adaptive_d_threshold`; the EMA lives on the device (base_model.py:55), the comparison is the reference's one host read per step
+        self.adaptive_d = bool(train_opt.adaptive_d)
+        self.adaptive_d_ema_decay = float(train_opt.adaptive_d_ema_decay)
+        self.adaptive_d_threshold = float(train_opt.adaptive_d_threshold)
+        self.l_g_gan_ema = torch.zeros(1, device=self.device)
         # options that change the step and are not built must not be ignored silently
         if train_opt.use_moa:
             raise NotImplementedError("use_moa (batch mixing augmentations, sr_model.py:434-450) is not on the HIP path yet")
@@ -326,6 +330,17 @@ class SRModel:
         return out
 
     # ------------------------------------------------------------------ THE HOT PATH ---------------------------
+    def _adaptive_d_skip(self, l_g_gan: Tensor) -> bool:
+        """sr_model.py:558-569: ema' = decay * ema + (1 - decay) * l_g_gan; skip the discriminator update of this step (and its scheduler step,
+        base_model.py:378) when ema' > ema * adaptive_d_threshold.  `l_g_gan` is a 1-element device tensor; the comparison is a host read,
+        as in the reference."""
+        ema = self.adaptive_d_ema_decay * self.l_g_gan_ema + (1.0 - self.adaptive_d_ema_decay) * l_g_gan
+        skip = bool(ema > self.l_g_gan_ema * self.adaptive_d_threshold)
+        self.l_g_gan_ema = ema
+        if skip and len(self.optimizers_skipped) > 1:
+            self.optimizers_skipped[1] = True
+        return skip
+
     def optimize_parameters(self, current_iter: int, current_accum_iter: int, apply_gradient: bool) -> None:
         assert self.lq is not None and self.gt is not None
         if self.net_d is not None and not hasattr(self.net_d, "forward_hip"):
@@ -367,7 +382,13 @@ class SRModel:
 
         lq_target = None
         for label, loss in self.losses.items():
-            w = abs(loss.loss_weight)
+            # IterativeLossWrapper (losses/__init__.py:79-110): the wrapped value is loss * schedule(iter), SRModel multiplies by abs(loss_weight)
+            # on top (sr_model.py:623-663) -- both are host scalars here and reach the head as one weight
+            wrapped = hasattr(loss, "loss_module")
+            head = loss.loss_module if wrapped else loss
+            wb = abs(loss.loss_weight)
+            sched = loss.step_weight(current_iter) if wrapped else 1.0
+            w = wb * sched
             target = gt
             if loss.loss_weight < 0:
                 # sr_model.py:503-516: a negative weight selects the bicubic-upsampled LQ as the target of that loss (its magnitude is the weight):
@@ -379,20 +400,23 @@ class SRModel:
                     lq_target = resize_pt(self.lq.float(), "bicubic", size=(self.lq.shape[2] * self.opt.scale, self.lq.shape[3] * self.opt.scale)).contiguous()
                 target = lq_target
             slot = len(keys)
-            if label == "l_g_gan" and hasattr(loss, "hip_value_and_grad") and hasattr(self.net_d, "forward_hip"):
+            if label == "l_g_gan" and hasattr(head, "hip_value_and_grad") and hasattr(self.net_d, "forward_hip"):
                 # generator-side GAN term, all on HIP: D(output) -> loss(pred, real) -> dL/dlogits -> D backward to the image only
                 logits = self.net_d.forward_hip(self.output, train=True)
                 g_logits = torch.empty_like(logits)
-                loss.hip_value_and_grad(logits, True, False, value_weight=w, value_out=scal[slot:], total_weight=w / acc, total_out=total,
+                head.hip_value_and_grad(logits, True, False, value_weight=w, value_out=scal[slot:], total_weight=w / acc, total_out=total,
                                         grad_weight=w / acc * S, grad=g_logits)
                 self.net_d.backward_hip(g_logits, param_grads=False, input_grad=gout, input_grad_accumulate=not first)
                 keys.append(label)
                 first = False
-            elif hasattr(loss, "hip_value_and_grad") and label != "l_g_gan":
+                if self.adaptive_d:
+                    # the reference's l_g_loss is the value before abs(loss_weight) (wrapped: times the schedule factor); scal[slot] holds it times wb
+                    skip_d_update = self._adaptive_d_skip(scal[slot:slot + 1] / wb)
+            elif hasattr(head, "hip_value_and_grad") and label != "l_g_gan":
                 # fused head.  scalar head: total += loss*w/acc ; dict head: total += v*w*acc  (sr_model.py:654-663)
-                is_dict = getattr(loss, "returns_dict", False)
+                is_dict = getattr(head, "returns_dict", False)
                 k = float(acc) if is_dict else 1.0 / acc
-                subs = loss.hip_value_and_grad(self.output, target, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
+                subs = head.hip_value_and_grad(self.output, target, value_weight=w, value_out=scal[slot:], total_weight=w * k, total_out=total,
                                                grad_weight=w * k * S, grad=gout, first=first)
                 keys += [f"{label}_{sub}" for sub in subs] if subs else [label]
                 first = False
@@ -401,14 +425,17 @@ class SRModel:
                 if out_leaf is None:
                     out_leaf = self.output.clone().requires_grad_(True) if hip_net else out
                 with torch.autocast(device_type="cuda", dtype=self.amp_dtype, enabled=self.use_amp):
+                    it = {"current_iter": current_iter} if wrapped else {}       # the wrapper's forward applies the schedule factor itself
                     if label == "l_g_gan":
                         assert self.net_d is not None
-                        val = loss(self.net_d(out_leaf), True, is_disc=False)
+                        val = loss(self.net_d(out_leaf), True, is_disc=False, **it)
+                        if self.adaptive_d:
+                            skip_d_update = self._adaptive_d_skip(val.detach().float().reshape(1))
                     else:
-                        val = loss(out_leaf, target)
+                        val = loss(out_leaf, target, **it)
                 items = [(f"{label}_{sub}", v, float(acc)) for sub, v in val.items()] if isinstance(val, dict) else [(label, val, 1.0 / acc)]
                 for key, v, k in items:
-                    wv = v * w
+                    wv = v * wb
                     foreign_total = wv * k if foreign_total is None else foreign_total + wv * k
                     scal[len(keys)] = wv.detach().float()
                     keys.append(key)
@@ -518,7 +545,9 @@ class SRModel:
         # ---- discriminator update (sr_model.py:725-808) ------------------------------------------------------------------
         cri_gan = self.losses.get("l_g_gan")
         if self.net_d is not None and cri_gan is not None and self.optimizer_d is not None and not skip_d_update:
-            wd = cri_gan.loss_weight   # the reference scales the D loss by the G-side weight (sr_model.py:763-768)
+            # the reference scales the D loss by the G-side weight, or by the schedule's weight of this iteration when wrapped (sr_model.py:763-768)
+            wd = cri_gan.get_current_weight(current_iter) if hasattr(cri_gan, "get_current_weight") else cri_gan.loss_weight
+            cri_gan = getattr(cri_gan, "loss_module", cri_gan)       # D-side values come from the unwrapped module (:739-741)
             if hasattr(self.net_d, "forward_hip") and hasattr(cri_gan, "hip_value_and_grad"):
                 dnet = self.net_d
                 for img, is_real, slot_ in ((gt, True, LD_REAL), (self.output, False, LD_FAKE)):
