@@ -253,7 +253,7 @@ def test_mfma_kernels_keep_accumulators_in_registers():
 
     B.build(verbose=False)
     res = json.load(open(B.RESOURCES))
-    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "wgrad_kernel", "window_attn", "dwconv", "winograd_f32"))}
+    hot = {k: v for k, v in res.items() if any(t in k for t in ("conv3x3_kernel_reg", "linear_kernel", "linear_dma_kernel", "wgrad_kernel", "wgrad_linear_kernel", "window_attn", "dwconv", "winograd_f32"))}
     assert len(hot) >= 20
     # The persistent 3x3 kernel carries three epilogue bodies since the store-wait rework (chunked with / without side inputs, and the
     # row-at-a-time one for ragged views); at its 256-VGPR limit the compiler parks 6-15 dwords of tile-loop state (piece offsets of the

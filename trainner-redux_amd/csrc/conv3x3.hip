@@ -145,6 +145,24 @@ __device__ __forceinline__ float gelu_grad(float x) {   // d/dx [x * Phi(x)], ex
     const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
     return cdf + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
+// Phi(x) and e^{-x^2/2} for the 16-bit straight-line token-GEMM forms: erfc(z) = poly(t) e^{-z^2}, t = 1 / (1 + 0.3275911 z), z = |x| / sqrt 2
+// (Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 on erf; measured in fp32 against float64: GELU 4.2e-7, GELU' 3.2e-7 absolute over [-12, 12]) --
+// one v_rcp and one v_exp instead of ocml's two-branch erff, whose ~60 divergent instructions per element made the fc1 Linear (GELU + saved
+// pre-activation) 14 us longer than the same GEMM without it at 32k tokens.  The results are rounded to bf16 / f16 right after.
+struct GeluParts { float cdf, e; };
+__device__ __forceinline__ GeluParts gelu_parts_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * z);
+    const float e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float h = 0.5f * poly * e;
+    return {x >= 0.f ? 1.f - h : h, e};
+}
+__device__ __forceinline__ float gelu_fast(float x) { return x * gelu_parts_fast(x).cdf; }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const GeluParts g = gelu_parts_fast(x);
+    return g.cdf + x * 0.3989422804014327f * g.e;
+}
 __device__ __forceinline__ float act_pre_grad(int mode, float m) {   // mask_mode 1 / 2 / 3: derivative of GELU / SiLU / Mish at the pre-activation m
     return mode == 1 ? gelu_grad(m) : mode == 2 ? silu_grad(m) : tr::mish_grad(m);
 }
@@ -768,8 +786,9 @@ int launch_reg(hipStream_t st, const ConvArgs& a, int ncg) {
 // The generic epilogue above walks a row in a ROLLED loop whose body branches at run time on activation, dtypes, side views and mask mode and, with a
 // residual, waits for one global round trip per 4-channel piece: measured on SwinIR-M's Linears it was 13 - 25 us of a 24 - 34 us launch
 // (tools/bench_linear.py with TRAINNER_CONV_DBG=4: 192 -> 540 24.3 -> 11.1 us, 192 -> 180 + residual 26.1 -> 7.2 us without it).  The five forms SwinIR's
-// forward and backward use get compile-time bodies: all side pieces (bias, residual, mask) of a row are requested back to back, then the row is
-// finished and stored; no run-time dispatch inside.  Semantics as conv_epilogue_impl: bias, [GELU with the pre-activation to out2], per-sample
+// forward and backward use get compile-time bodies: all side pieces (residual, mask) of a row are requested back to back, then the row is
+// finished and stored; no run-time dispatch inside.  The bias is not a side piece: the kernels seed their accumulators with it when a form is set
+// (12 float4 of bias per row next to 12 of residual and the 96 accumulator registers spilled 93 dwords at NT = 3).  Semantics as conv_epilogue_impl: bias, [GELU with the pre-activation to out2], per-sample
 // scale, residual, GELU-derivative mask.  Host-checked: cout % 4 == 0, vector-accessible views, w == 32.
 enum { LF_PLAIN_CD = 0, LF_PLAIN_F32 = 1, LF_RES_F32 = 2, LF_GELU_CD = 3, LF_MASKG_CD = 4 };
 
@@ -806,7 +825,6 @@ __device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2]
                     make_float4(acc[r][t][q * 4 + 0], acc[r][t][q * 4 + 1], acc[r][t][q * 4 + 2], acc[r][t][q * 4 + 3]);
         __builtin_amdgcn_wave_barrier();
         // side pieces of the whole row first: one memory latency per row
-        float4 b4[ITER];
         float4 side[(FORM == LF_RES_F32) ? ITER : 1];
         uint2 mk[(FORM == LF_MASKG_CD) ? ITER : 1];
 #pragma unroll
@@ -814,7 +832,7 @@ __device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2]
             const int idx = i * 64 + l;
             const int p = idx / SEGS, seg = idx - p * SEGS;
             const int co = min(cbase + seg * 4, a.cout - 4);            // clamped: loads stay in range, stores are masked below
-            b4[i] = a.bias ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            (void)co;
             if constexpr (FORM == LF_RES_F32) side[i] = *(const float4*)((const float*)a.res1.ptr + (tok0 + p) * a.res1.cstride + a.res1.coff + co);
             if constexpr (FORM == LF_MASKG_CD) mk[i] = *(const uint2*)((const unsigned short*)a.mask.ptr + (tok0 + p) * a.mask.cstride + a.mask.coff + co);
         }
@@ -825,13 +843,13 @@ __device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2]
             const int p = idx / SEGS, seg = idx - p * SEGS;
             const int co = cbase + seg * 4;
             const float4 raw = *(const float4*)(strip + p * ROWB + seg * 16);
-            float v[4] = {raw.x + b4[i].x, raw.y + b4[i].y, raw.z + b4[i].z, raw.w + b4[i].w};
+            float v[4] = {raw.x, raw.y, raw.z, raw.w};            // the bias seeded the accumulators (lin_seed_bias)
             const bool ok = co < a.cout;
             const int64_t tok = tok0 + p;
             if constexpr (FORM == LF_GELU_CD) {
                 if (ok) *(uint2*)((unsigned short*)a.out2.ptr + tok * a.out2.cstride + a.out2.coff + co) = lin_pack4<CT>(v[0], v[1], v[2], v[3]);      // pre-activation
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = 0.5f * v[k] * (1.f + erff(v[k] * 0.70710678118654752f));
+                for (int k = 0; k < 4; ++k) v[k] = gelu_fast(v[k]);
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] *= ss;
@@ -841,7 +859,7 @@ __device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2]
             }
             if constexpr (FORM == LF_MASKG_CD) {
                 const float4 m = lin_unpack4<CT>(mk[i]);
-                v[0] *= gelu_grad(m.x); v[1] *= gelu_grad(m.y); v[2] *= gelu_grad(m.z); v[3] *= gelu_grad(m.w);
+                v[0] *= gelu_grad_fast(m.x); v[1] *= gelu_grad_fast(m.y); v[2] *= gelu_grad_fast(m.z); v[3] *= gelu_grad_fast(m.w);
             }
             if (ok) {
                 if constexpr (FORM == LF_PLAIN_F32 || FORM == LF_RES_F32) {
@@ -857,6 +875,21 @@ __device__ __forceinline__ void lin_epi_form(const ConvArgs& a, f32x16 (&acc)[2]
         }
         __builtin_amdgcn_wave_barrier();       // the strip is rewritten by the next row
     }
+}
+
+// accumulator seed of the straight-line forms: lane (lr, lh) holds channels t * 32 + q * 8 + lh * 4 + k of its pixel in acc[.][t][q * 4 + k]
+template <int NT>
+__device__ __forceinline__ void lin_seed_bias(const ConvArgs& a, f32x16 (&acc)[2][NT], int cbase, int lh) {
+    if (!a.bias) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int co = cbase + t * 32 + q * 8 + lh * 4;
+            const float4 b = co < a.cout ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { acc[r][t][q * 4 + 0] = b.x; acc[r][t][q * 4 + 1] = b.y; acc[r][t][q * 4 + 2] = b.z; acc[r][t][q * 4 + 3] = b.w; }
+        }
 }
 
 template <int CT, int NT>
@@ -936,6 +969,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_kernel(ConvArgs a, int nbl
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
     const bool wave_active = (y0 + wr * R) < a.h;
+    if constexpr (CT == TR_BF16 || CT == TR_F16) { if (a.lin_form >= 0) lin_seed_bias<NT>(a, acc, (cb * 2 + wc) * NT * 32, lh); }
     TR_LIN_ISSUE(0)
     for (int ch = 0; ch < a.nchunks; ++ch) {
         __syncthreads();
@@ -1032,6 +1066,7 @@ __global__ __launch_bounds__(NTHREADS, S <= 2 ? 3 : 2) void linear_dma_kernel(Co
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
     const bool wave_active = (y0 + wr * R) < a.h;
+    if (a.lin_form >= 0) lin_seed_bias<NT>(a, acc, (cb * 2 + wc) * NT * 32, lh);
     const int nch = a.nchunks;
     for (int c = 0; c < P && c < nch; ++c) issue(c);
     for (int ch = 0; ch < nch; ++ch) {
