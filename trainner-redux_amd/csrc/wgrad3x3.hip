@@ -315,6 +315,98 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 
+// The same reduction on 16-byte partial reads (cin % 4 == 0): a lane owns four consecutive input channels of one (co, tap) row -- contiguous in the
+// partial blocks ([..][tap][ci 32]) -- so a block covers 256 outputs and every load chain carries four times the bytes (the 4-byte form read the
+// 37 MB of SPAN's 104 -> 104 partials at 1.4 TB/s, and SwinIR-M's 156 reductions per step cost 9.5 us each).  Same slot order per output: bitwise
+// equal to the scalar form.  `vst`: dw rows are 16-byte addressable (taps == 1, ld % 4 == 0, aligned base) -> one float4 store.
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+                                                                int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
+                                                                const float* __restrict__ db_partials, float* __restrict__ db, int ld, int vst) {
+    if ((int)blockIdx.x >= nb_dw) {
+        const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
+        if (co >= cout) return;
+        const int cg = co / cgw, col = co - cg * cgw;
+        const float* p = db_partials + (int64_t)cg * cgw + col;
+        const int64_t stride = (int64_t)ncg * cgw;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 4 <= nslots; k += 4) {
+            s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
+        }
+        for (; k < nslots; ++k) s0 += p[k * stride];
+        const float s = (s0 + s1) + (s2 + s3);
+        db[co] = accumulate ? db[co] + s : s;
+        return;
+    }
+    __shared__ float4 red[4][64];
+    const int64_t total4 = (int64_t)cout * taps * cin / 4;
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total4; base += (int64_t)nb_dw * 64) {
+        const int64_t i = (base + l) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int ci = 0, tap = 0, co = 0;
+        const bool on = base + l < total4;
+        if (on) {
+            ci = (int)(i % cin);
+            tap = (int)((i / cin) % taps);
+            co = (int)(i / ((int64_t)cin * taps));
+            const int chunk = ci / CKW, cil = ci - chunk * CKW;
+            const int cg = co / cgw, col = co - cg * cgw;
+            const int64_t blk = (int64_t)cgw * taps * CKW;
+            const float* p = partials + ((int64_t)chunk * ncg + cg) * blk + ((int64_t)col * taps + tap) * CKW + cil;
+            const int64_t stride = (int64_t)nchunks * ncg * blk;
+            float4 s0 = s, s1 = s, s2 = s, s3 = s;   // fixed association per component: the scalar kernel's
+#define TR_ADD4(acc, q) { const float4 v = *(const float4*)(q); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            int k = wv;
+            for (; k + 12 < nslots; k += 16) {
+                TR_ADD4(s0, p + (k + 0) * stride) TR_ADD4(s1, p + (k + 4) * stride) TR_ADD4(s2, p + (k + 8) * stride) TR_ADD4(s3, p + (k + 12) * stride)
+            }
+            for (; k < nslots; k += 4) TR_ADD4(s0, p + k * stride)
+#undef TR_ADD4
+            s = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+        }
+        red[wv][l] = s;
+        __syncthreads();
+        if (wv == 0 && on) {
+            const float4 a = red[0][l], b = red[1][l], c = red[2][l], d = red[3][l];
+            float t[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+            if (vst) {
+                float4* o = (float4*)(dw + (int64_t)co * ld + ci);
+                float4 v = make_float4(t[0], t[1], t[2], t[3]);
+                if (accumulate) { const float4 u = *o; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+                *o = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float* o = dw + ((int64_t)co * ld + ci + e) * taps + tap;
+                    *o = accumulate ? *o + t[e] : t[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// second-stage launch shared by every weight-gradient kernel
+static void launch_wgrad_reduce(hipStream_t st, const float* partials, float* dw, int cin, int cout, int nslots, int nchunks, int ncg, int cgw, int accumulate,
+                                int taps, const float* db_partials, float* db, int ld) {
+    const int64_t total = (int64_t)cout * taps * cin;
+    const int nb_db = db ? (cout + 255) / 256 : 0;
+    if (cin % 4 == 0 && ((uintptr_t)partials % 16) == 0) {
+        int64_t b = (total / 4 + 63) / 64;
+        if (b > 8192) b = 8192;
+        const int vst = taps == 1 && ld % 4 == 0 && ((uintptr_t)dw % 16) == 0;
+        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate,
+                           taps, (int)b, db_partials, db, ld, vst);
+        return;
+    }
+    int64_t b = (total + 63) / 64;
+    if (b > 8192) b = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps,
+                       (int)b, db_partials, db, ld);
+}
+
+
 // ---- nn.Linear weight gradient (ksize 1, direct input) as a split-K GEMM ----------------------------------------------------------
 // dW[co][ci] = sum_t gy[t][co] x[t][ci]: M = cout, N = cin, K = tokens.  The 3x3 kernel's tiling (one 32-channel input chunk x one
 // 64-channel output group per workgroup) has no tap reuse to amortise its loads at ksize 1 (measured 110 TFLOP/s on SwinIR-M's qkv).
@@ -575,12 +667,8 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
         else hipLaunchKernelGGL(wgrad_linear_kernel<TR_F16>, dim3(q.nslots, q.nib, q.ncb), dim3(256), lds, st, la);
         int rc = tr::launch_status("tr_wgrad3x3(linear)");
         if (rc) return rc;
-        const int64_t total = (int64_t)d->cout * d->cin;
-        int64_t b = (total + 63) / 64;
-        if (b > 8192) b = 8192;
-        const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, q.nslots, q.nchunks,
-                           q.ncg, 64, d->accumulate, 1, (int)b, d->partials + q.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
+        launch_wgrad_reduce(st, d->partials, d->dw, d->cin, d->cout, q.nslots, q.nchunks, q.ncg, 64, d->accumulate, 1, d->partials + q.dw_floats, d->db,
+                            d->dw_ld > 0 ? d->dw_ld : d->cin);
         return tr::launch_status("tr_wgrad3x3(linear reduce)");
     }
     // one round of RESIDENT workgroups (more would run as a half-empty second round): 3 per CU for the 32-wide bf16 variant
@@ -612,12 +700,8 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
         rc = tr::wgrad3x3_ring(st, d, ar, rp);
         if (rc > 0) return rc;
         if (rc == 0) {
-            const int64_t total = (int64_t)d->cout * 9 * d->cin;
-            int64_t b = (total + 63) / 64;
-            if (b > 8192) b = 8192;
-            const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, rp.slots_eff, rp.nchunks,
-                               rp.ncg, rp.cgw, d->accumulate, 9, (int)b, d->partials + rp.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
+            launch_wgrad_reduce(st, d->partials, d->dw, d->cin, d->cout, rp.slots_eff, rp.nchunks, rp.ncg, rp.cgw, d->accumulate, 9, d->partials + rp.dw_floats,
+                                d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
             return tr::launch_status("tr_wgrad3x3(ring reduce)");
         }
     }
@@ -634,12 +718,8 @@ extern "C" int tr_wgrad3x3(void* stream, const tr_wgrad3x3_desc* d) {
     {
         const int taps = d->ksize * d->ksize;
         const int mult = d->ksize == 1 ? 3 : 1;
-        const int64_t total = (int64_t)d->cout * taps * d->cin;
-        int64_t b = (total + 63) / 64;
-        if (b > 8192) b = 8192;
-        const int nb_db = d->db ? (d->cout + 255) / 256 : 0;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult,
-                           p.nchunks, p.ncg, p.cgw, d->accumulate, taps, (int)b, d->partials + p.dw_floats, d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
+        launch_wgrad_reduce(st, d->partials, d->dw, d->cin, d->cout, p.nslots * mult, p.nchunks, p.ncg, p.cgw, d->accumulate, taps, d->partials + p.dw_floats,
+                            d->db, d->dw_ld > 0 ? d->dw_ld : d->cin);
         rc = tr::launch_status("tr_wgrad3x3(reduce)");
     }
     return rc;
@@ -673,12 +753,8 @@ extern "C" int tr_wgrad3x3_multi(void* stream, const tr_wgrad3x3_desc* descs, in
         const tr_wgrad3x3_desc& d = descs[k];
         const int nchunks = (d.cin + 31) / 32, ncg = (d.cout + 31) / 32;
         const size_t dw_floats = (size_t)nslots * nchunks * ncg * 32 * 9 * 32;
-        const int64_t total = (int64_t)d.cout * 9 * d.cin;
-        int64_t b = (total + 63) / 64;
-        if (b > 8192) b = 8192;
-        const int nb_db = d.db ? (d.cout + 255) / 256 : 0;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, (hipStream_t)stream, d.partials, d.dw, d.cin, d.cout, nslots, nchunks, ncg,
-                           32, d.accumulate, 9, (int)b, d.partials + dw_floats, d.db, d.dw_ld > 0 ? d.dw_ld : d.cin);
+        launch_wgrad_reduce((hipStream_t)stream, d.partials, d.dw, d.cin, d.cout, nslots, nchunks, ncg, 32, d.accumulate, 9, d.partials + dw_floats, d.db,
+                            d.dw_ld > 0 ? d.dw_ld : d.cin);
     }
     return tr::launch_status("tr_wgrad3x3_multi(reduce)");
 }
