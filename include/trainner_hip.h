@@ -55,7 +55,7 @@ int         tr_abi_version(void);
 const char* tr_last_error(void);
 /* Kernel-selection switches (no reference counterpart: cuDNN picks its algorithms behind torch.backends.cudnn.benchmark, train.py:276-283).
  * Keys: "conv_impl" (0 automatic | 1 register-staged kernels | 2 LDS-DMA ring kernel whenever eligible), "ring_cfg" (-1 automatic | 33 / 32 / 31 |
- * 0), "ring_generic" (0 | 1), "wgrad_impl" (0 | 1 | 2), "wgrad_multi" (1 | 0), "dgrad_image_ref" (0 | 1), "linear_impl" (0 LDS-DMA ring | 1 register-staged token GEMM), "linear_epilogue" (0 straight-line forms | 1 generic); read-only records of the last
+ * 0), "ring_generic" (0 | 1), "wgrad_impl" (0 | 1 | 2), "wgrad_multi" (1 | 0), "wgrad_reduce" (0 16-byte reads | 1 4-byte form), "dgrad_image_ref" (0 | 1), "linear_impl" (0 LDS-DMA ring | 1 register-staged token GEMM), "linear_epilogue" (0 straight-line forms | 1 generic); read-only records of the last
  * tr_conv3x3 launch: "last_conv_family" (1 register-staged, 2 LDS-DMA two-stage, 3 token GEMM, 4 ring, 5 token GEMM with LDS-DMA staging), "last_conv_instance", and the counter "ring_launches".  Initial values
  * come from the TRAINNER_* environment variables once, at load time; launches never read the environment.  Process-wide, not thread-safe
  * against concurrent launches (the step is driven by one host thread, SURVEY.md section 8b "Threading").

@@ -17,6 +17,7 @@ struct Tune {
     int ring_generic;     // 1 = generic epilogue body instead of the fast forms
     int wgrad_impl;       // tr_wgrad3x3: 0 = automatic, 1 = register-staged, 2 = ring whenever eligible
     int wgrad_multi;      // tr_wgrad3x3_multi: 1 = one fused launch per dense block when eligible, 0 = one launch per conv
+    int wgrad_reduce;     // second stage of the weight gradients: 0 = 16-byte partial reads where cin % 4 == 0, 1 = the 4-byte form
     int dgrad_image_ref;  // tr_conv3x3_dgrad_image: 1 = per-pixel reference kernel
     int linear_epilogue;  // token GEMM epilogue: 0 = straight-line forms where they apply, 1 = always the generic epilogue
     int linear_impl;      // token GEMM (ksize 1 on a 32-wide token grid), 16-bit: 0 = LDS-DMA staged ring, 1 = register-staged one-chunk prefetch

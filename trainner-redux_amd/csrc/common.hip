@@ -25,6 +25,7 @@ Tune& tune() {
         x.ring_generic = getenv("TRAINNER_RING_GENERIC") ? 1 : 0;
         x.wgrad_impl = env_choice("TRAINNER_WGRAD_IMPL", "reg", "ring");
         x.wgrad_multi = (getenv("TRAINNER_WGRAD_MULTI") && !strcmp(getenv("TRAINNER_WGRAD_MULTI"), "0")) ? 0 : 1;
+        x.wgrad_reduce = (getenv("TRAINNER_WGRAD_REDUCE") && !strcmp(getenv("TRAINNER_WGRAD_REDUCE"), "scalar")) ? 1 : 0;
         x.dgrad_image_ref = getenv("TRAINNER_DGRAD_IMAGE_REF") ? 1 : 0;
         x.linear_impl = (getenv("TRAINNER_LINEAR_IMPL") && !strcmp(getenv("TRAINNER_LINEAR_IMPL"), "reg")) ? 1 : 0;
         return x;
@@ -37,7 +38,7 @@ namespace {
 int* tune_slot(const char* key) {
     tr::Tune& t = tr::tune();
     struct { const char* k; int* p; } tab[] = {{"conv_impl", &t.conv_impl}, {"ring_cfg", &t.ring_cfg}, {"ring_generic", &t.ring_generic},
-                                              {"wgrad_impl", &t.wgrad_impl}, {"wgrad_multi", &t.wgrad_multi}, {"dgrad_image_ref", &t.dgrad_image_ref},
+                                              {"wgrad_impl", &t.wgrad_impl}, {"wgrad_multi", &t.wgrad_multi}, {"wgrad_reduce", &t.wgrad_reduce}, {"dgrad_image_ref", &t.dgrad_image_ref},
                                               {"linear_impl", &t.linear_impl}, {"linear_epilogue", &t.linear_epilogue},
                                               {"last_conv_family", &t.last_conv_family}, {"last_conv_instance", &t.last_conv_instance},
                                               {"ring_launches", &t.ring_launches}};

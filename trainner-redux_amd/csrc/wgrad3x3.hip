@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 
 // The same reduction on 16-byte partial reads (cin % 4 == 0): a lane owns four consecutive input channels of one (co, tap) row -- contiguous in the
-// partial blocks ([..][tap][ci 32]) -- so a block covers 256 outputs and every load chain carries four times the bytes (the 4-byte form read the
-// 37 MB of SPAN's 104 -> 104 partials at 1.4 TB/s, and SwinIR-M's 156 reductions per step cost 9.5 us each).  Same slot order per output: bitwise
+// partial blocks ([..][tap][ci 32]) -- so a block covers 256 outputs and every load chain carries four times the bytes (SwinIR-M's 156 reductions per step cost 9.5 us each
+// in the 4-byte form).  Same slot order per output: bitwise
 // equal to the scalar form.  `vst`: dw rows are 16-byte addressable (taps == 1, ld % 4 == 0, aligned base) -> one float4 store.
 __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
                                                                 int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
@@ -392,7 +392,9 @@ static void launch_wgrad_reduce(hipStream_t st, const float* partials, float* dw
                                 int taps, const float* db_partials, float* db, int ld) {
     const int64_t total = (int64_t)cout * taps * cin;
     const int nb_db = db ? (cout + 255) / 256 : 0;
-    if (cin % 4 == 0 && ((uintptr_t)partials % 16) == 0) {
+    // same-box A/B (bench.py, MI355X): token GEMMs (taps 1, float4 stores) +1.1 % on SwinIR-M's step; 3x3 weights (stride-9 stores either way) within
+    // noise on MoSR / SPAN and -0.5 % on ESRGAN's L1-only step, so only the ksize-1 reductions take the 16-byte form
+    if (tr::tune().wgrad_reduce == 0 && taps == 1 && cin % 4 == 0 && ((uintptr_t)partials % 16) == 0) {
         int64_t b = (total / 4 + 63) / 64;
         if (b > 8192) b = 8192;
         const int vst = taps == 1 && ld % 4 == 0 && ((uintptr_t)dw % 16) == 0;
