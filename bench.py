@@ -376,6 +376,11 @@ def roofline(args, agg, dt, n, s):
                   "rate of the convolution itself (DESIGN.md section 4)") if mfma else
                  "achieved / frac = algorithmic bytes (input once + every output / side view once) over the launch time, against 8 TB/s",
          "all": table}
+    if r["traffic"] is not None:
+        # the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) count every L2 miss, Infinity-Cache hits included
+        r["traffic_note"] = ("traffic = L2-miss bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes; Infinity-Cache hits are counted.  "
+                             + ("Per layer (profiles/r03_w43_traffic_per_layer.txt) it is input x 1.2 + output + the transformed-weight array re-streamed by each XCD "
+                                "once per round of tiles (<= 37.7 MB, cache resident): the input is NOT re-fetched per output group" if key[0] == "f32w4" else ""))
     return r
 
 
