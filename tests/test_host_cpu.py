@@ -379,3 +379,12 @@ def test_iterative_loss_wrapper_matches_reference_golden():
     assert isinstance(wrapped, IterativeLossWrapper) and type(wrapped.loss_module).__name__ == "L1Loss"
     assert wrapped.loss_weight == 0.5 and wrapped.get_current_weight(6) == 0.75 and wrapped.get_current_weight(3) == 0.0
     assert not isinstance(build_loss({"type": "l1loss", "loss_weight": 0.5}), IterativeLossWrapper)
+
+
+def test_library_binds_to_the_hip_runtime_torch_already_mapped(built):
+    """`_lib.lib()` in a fresh interpreter that has NOT imported torch yet (what `__graft_entry__.build()` does before `smoke()` in one process): the
+    process must end up with ONE libamdhip64 -- torch's bundled copy -- or every launch fails with "no ROCm-capable device is detected"."""
+    code = ("import sys; sys.path.insert(0, %r); import trainner_redux_amd._lib as L; L.lib(); import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(libs); assert len(libs) == 1, libs" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -201,6 +201,13 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
             "This package has no non-HIP execution path."
         )
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and libtorch_hip asks for it as "libamdhip64.so":
+    # when THIS library is loaded first, its NEEDED libamdhip64.so.7 resolves to /opt/rocm's copy, torch then maps its own next to it, and the process
+    # holds two HIP runtimes -- every launch from here fails with "no ROCm-capable device is detected" (seen with build() + smoke() in one process).
+    # Loaded after torch, the same NEEDED entry binds to the runtime torch already mapped: one runtime, shared streams.  A host without torch is
+    # not affected (it has one runtime to begin with).
+    import torch  # noqa: F401
+
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         try:
