@@ -384,6 +384,12 @@ def roofline(args, agg, dt, n, s):
     return r
 
 
+# TRAINNER_BENCH_REHEARSE=1: run the multi-rank code path (own ranks, barrier + max-over-ranks timing, bucketed gradient exchange, rank-0 JSON line) on a
+# box with fewer GPUs than ranks -- the ranks share the devices and talk over gloo.  The numbers of such a run mean nothing; it exists so that the
+# path the driver launches on an 8-GPU node is executed by a test on the one-GPU box.
+REHEARSE = os.environ.get("TRAINNER_BENCH_REHEARSE") == "1"
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL) as children through torch.distributed.run --
     decided before this process touches the GPU -- and relay their output; rank 0 prints the JSON line.  The ranks see the same argv."""
@@ -391,7 +397,7 @@ def spawn_ranks(n: int) -> int:
     import subprocess
 
     ndev = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if ndev < n:
+    if ndev < n and not REHEARSE:
         print(json.dumps({"error": f"--gpus {n} asked for, {ndev} visible"}))
         return 2
     with socket.socket() as sk:
@@ -417,10 +423,12 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "bench.py needs an MI355X; this package has no CPU execution path"}))
         sys.exit(2)
+    if REHEARSE:        # one-GPU rehearsal of the N-rank path (tests/test_dp_gpu.py): the ranks share the visible devices, gloo instead of RCCL
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group("gloo" if REHEARSE else "nccl")
         world = dist.get_world_size()
     dev = torch.device("cuda", local_rank)
 

@@ -59,3 +59,22 @@ def test_two_ranks_equal_one_rank_with_twice_the_batch(cuda, tmp_path):
     # accumulation over two micro-batches of the same half batch == twice its gradient / 2 -> the same averaged gradient as step 1 of `snap`
     e = rel_l2(two["snap_accum"]["m_g"], two["snap"]["m_g"])
     print(f"2 ranks vs 1 rank: first-moment rel-L2 G {rel_l2(two['snap']['m_g'], one['m_g']):.2e} D {rel_l2(two['snap']['m_d'], one['m_d']):.2e}; accum-2 vs accum-1 {e:.2e}")
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_whole_job(cuda):
+    """`python bench.py --gpus 2` without a launcher (what the driver's scaling run does with N = 2, 4, 8): the parent starts the ranks through
+    torch.distributed.run, every rank runs the timed steps between barriers, the time is the max over ranks and rank 0 prints ONE JSON line whose value is
+    the whole job's images/s.  Rehearsed on the one GPU of this box (TRAINNER_BENCH_REHEARSE=1: shared device, gloo) -- the numbers mean nothing here."""
+    import json
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TRAINNER_BENCH_REHEARSE="1", TRAINNER_BUCKET_MB="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--blocks", "2", "--batch", "2", "--lq", "32",
+           "--no-cpu-baseline", "--no-variants", "--no-loader"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0 and abs(d["value"] - 4 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    assert "roofline" in d and "cpu_baseline" not in d
