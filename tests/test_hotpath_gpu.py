@@ -74,3 +74,55 @@ def test_fast_kernel_selection_matches_the_plain_paths(monkeypatch):
     cos = (torch.dot(w_f.double(), w_p.double()) / (w_f.double().norm() * w_p.double().norm())).item()
     print(f"gradient rel-L2 {rel:.3e}, cosine {cos:.8f}, losses {log_f} vs {log_p}")
     assert rel < 5e-4 and cos > 0.999999, (rel, cos)        # measured 5.0e-5 / 1.00000000
+
+
+def test_bench_size_batch_is_the_union_of_its_halves():
+    """BASELINE configs[1] at its FULL size (batch 16, 256 -> 1024, 23 blocks, L1 + fp32 perceptual, bf16) -- the size no oracle run reaches -- through
+    a size-independent property: samples do not interact, so (a) the generator's output for the batch is, bit for bit, the outputs of its two halves,
+    whatever tiles the persistent kernels deal to which workgroup, and (b) the parameter gradient of the batch-16 step is the mean of the two batch-8
+    steps' gradients (d loss / d output differs by an exact factor 2, which 16-bit rounding commutes with; only the fp32 summation order over
+    samples differs) and its loss terms are the means of theirs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench
+    from trainner_redux_amd.models import build_model
+
+    for k in SWITCHES:
+        os.environ.pop(k, None)
+    argv = sys.argv
+    sys.argv = ["bench.py", "--batch", "16", "--lq", "256"]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    torch.manual_seed(1024)
+    model = build_model(bench.make_opt(args))
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(16, 3, 1024, 1024, generator=g).to(dev)
+    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
+    net = model.net_g
+    _, garr = net.flat_parameters()
+
+    def grads_of(parts):
+        garr.zero_()
+        model.reset_current_log()
+        outs = []
+        for sl in parts:
+            model.feed_data({"lq": lq[sl], "gt": gt[sl]})
+            model.optimize_parameters(1, 0, False)          # accumulate only: the weights stay where they are
+            outs.append(model.output.clone())
+        log = {k: float(v) for k, v in model.get_current_log().items()}
+        torch.cuda.synchronize()
+        return torch.cat(outs), garr.clone(), log
+
+    out16, g16, log16 = grads_of([slice(0, 16)])
+    out88, g88, log88 = grads_of([slice(0, 8), slice(8, 16)])
+    assert torch.equal(out16, out88), (out16 - out88).abs().max().item()
+    for k in log16:
+        if k.startswith("l_g_"):
+            assert abs(log16[k] - log88[k]) <= 2e-6 * abs(log88[k]), (k, log16[k], log88[k])
+    half = g88.double() * 0.5
+    rel = ((g16.double() - half).norm() / half.norm()).item()
+    print(f"batch 16 vs 8 + 8: outputs identical, gradient rel-L2 {rel:.3e}, losses {log16}")
+    assert rel < 2e-5, rel
