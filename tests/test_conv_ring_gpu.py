@@ -79,7 +79,7 @@ GEOMS = [(1, 17, 33), (2, 40, 72), (1, 9, 100), (3, 16, 32)]
 @pytest.mark.parametrize("compute_name", ["bf16", "f16"])
 @pytest.mark.parametrize("geom", GEOMS)
 @pytest.mark.parametrize("chan", [(64, 32, -1), (96, 32, -1), (128, 32, -1), (64, 32, 32), (96, 32, 31), (128, 32, 0), (160, 32, -1), (192, 64, -1), (64, 64, -1),
-                                  (64, 128, -1)])
+                                  (64, 128, -1), (64, 96, -1), (96, 160, -1)])
 def test_ring_forward_lrelu_dense_slice(cuda, compute_name, geom, chan):
     """RDB conv1-4 / conv of the tail: bias + LeakyReLU(0.2), 16-bit output into the next channel slice of the SAME 192(+)-channel buffer the
     input is a prefix of (in-place torch.cat, scunet_aaf6aa_arch.py:328-334) -- fast epilogue form 0."""
@@ -257,6 +257,44 @@ def test_ring_conv5_residual_streams(cuda, compute_name, case):
         got2 = nxt.float().cpu()
         _check16(nchw(got2[..., :cout]), ref, dt, case)
         assert torch.all(got2[..., cout:] == 5.0)
+
+
+@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
+@pytest.mark.parametrize("form", ["plain", "mask", "res"])
+@pytest.mark.parametrize("chan", [(64, 96), (96, 160), (192, 96)])
+def test_ring_64_wide_group_with_half_a_last_group(cuda, compute_name, form, chan):
+    """cout = 64 k + 32 on the 64-wide instances (MoSR: fc2's input gradient 64 -> 96; gated blocks with hid = 96): the last output group has ONE
+    32-channel tile.  The fast epilogue forms checked lane offsets against cout for the group's first tile only and stored the absent second tile
+    32 channels further on -- channels 0-31 of the NEXT pixel in a buffer whose channel stride equals cout (found in round 3 by the batch-halves
+    property test; MoSR's bf16 gradients were wrong by up to 60 % per tensor).  Tight buffers (stride == cout), every fast form, against F.conv2d."""
+    from trainner_redux_amd import _lib as L, ops
+
+    n, h, w = 2, 24, 40
+    cin, cout = chan
+    compute, dt = _ct(L, compute_name)
+    g = torch.Generator().manual_seed(7 + cin + cout)
+    x = _rnd(torch.randn(n, cin, h, w, generator=g), dt)
+    wt = _rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dt)
+    b = torch.randn(cout, generator=g)
+    pre = _rnd(torch.randn(n, cout, h, w, generator=g), dt)
+    r1 = torch.randn(n, cout, h, w, generator=g)
+    v = F.conv2d(x, wt, b, padding=1)
+    ref = {"plain": v, "mask": v * torch.where(pre > 0, 1.0, 0.2), "res": v * 0.2 + r1}[form]
+    xd, bias = nhwc(x).to(cuda, dt), b.to(cuda)
+    wp = _pack(ops, wt.to(cuda), cin, cout, compute, cuda)
+    out = torch.full((n, h, w, cout), 3.0, dtype=torch.float32 if form == "res" else dt, device=cuda)
+    out2 = torch.full((n, h, w, cout), 5.0, dtype=dt, device=cuda)
+    pred, r1d = nhwc(pre).to(cuda, dt), nhwc(r1).to(cuda)
+    kw = {"plain": {}, "mask": dict(mask=ops.view(pred), mask_slope=0.2), "res": dict(res1=ops.view(r1d), scale1=0.2, out2=ops.view(out2), out2_scale=1.0)}[form]
+    with ops.tuned(conv_impl=2):
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out), wpacked=wp, bias=bias, **kw)
+    inst = _ring(ops)
+    assert inst // 10000 == 2 and inst % 10 == {"plain": 0, "mask": 1, "res": 2}[form], inst
+    if form == "res":
+        assert rel_l2(nchw(out.cpu()), ref) < 2e-6
+        _check16(nchw(out2.float().cpu()), ref, dt, (form, chan))
+    else:
+        _check16(nchw(out.float().cpu()), ref, dt, (form, chan))
 
 
 @pytest.mark.parametrize("compute_name", ["bf16", "f16"])

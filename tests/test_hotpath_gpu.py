@@ -76,12 +76,15 @@ def test_fast_kernel_selection_matches_the_plain_paths(monkeypatch):
     assert rel < 5e-4 and cos > 0.999999, (rel, cos)        # measured 5.0e-5 / 1.00000000
 
 
-def test_bench_size_batch_is_the_union_of_its_halves():
-    """BASELINE configs[1] at its FULL size (batch 16, 256 -> 1024, 23 blocks, L1 + fp32 perceptual, bf16) -- the size no oracle run reaches -- through
-    a size-independent property: samples do not interact, so (a) the generator's output for the batch is, bit for bit, the outputs of its two halves,
-    whatever tiles the persistent kernels deal to which workgroup, and (b) the parameter gradient of the batch-16 step is the mean of the two batch-8
-    steps' gradients (d loss / d output differs by an exact factor 2, which 16-bit rounding commutes with; only the fp32 summation order over
-    samples differs) and its loss terms are the means of theirs."""
+@pytest.mark.parametrize("flags,batch,lq", [("", 16, 256), ("--arch swinir_m", 8, 64), ("--arch span --compute f16", 64, 64), ("--arch mosr --compute f16", 64, 64)],
+                         ids=["configs1_esrgan", "configs3_swinir_m", "configs4_span_f16", "configs4_mosr_f16"])
+def test_bench_size_batch_is_the_union_of_its_halves(flags, batch, lq):
+    """Every bench workload at its FULL size (configs[1]: batch 16, 256 -> 1024, 23 blocks, L1 + fp32 perceptual, bf16; configs[3] SwinIR-M batch 8; configs[4]
+    SPAN / MoSR 2x fp16 batch 64) -- sizes no oracle run reaches -- through a size-independent property: samples do not interact, so (a) the generator's
+    output for the batch is, bit for bit, the outputs of its two halves, whatever tiles the persistent kernels deal to which workgroup, and (b) the
+    parameter gradient of the full-batch step is the mean of the two half-batch steps' gradients (d loss / d output differs by an exact factor 2, which
+    16-bit rounding commutes with; only the fp32 summation order over samples differs) and its loss terms are the means of theirs.
+    (SwinIR's stochastic depth is switched off here: its keep masks are drawn per call.)"""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     import bench
@@ -90,18 +93,21 @@ def test_bench_size_batch_is_the_union_of_its_halves():
     for k in SWITCHES:
         os.environ.pop(k, None)
     argv = sys.argv
-    sys.argv = ["bench.py", "--batch", "16", "--lq", "256"]
+    sys.argv = ["bench.py", *flags.split(), "--batch", str(batch), "--lq", str(lq)]
     try:
         args = bench.parse()
     finally:
         sys.argv = argv
     torch.manual_seed(1024)
     model = build_model(bench.make_opt(args))
+    net = model.net_g
+    if hasattr(net, "drop_path_rate"):
+        net.drop_path_rate = 0.0
+    sc, h = args.scale, batch // 2
     dev = torch.device("cuda")
     g = torch.Generator().manual_seed(11)
-    gt = torch.rand(16, 3, 1024, 1024, generator=g).to(dev)
-    lq = torch.nn.functional.interpolate(gt, scale_factor=0.25, mode="bicubic", antialias=True).clamp(0, 1)
-    net = model.net_g
+    gt = torch.rand(batch, 3, sc * lq, sc * lq, generator=g).to(dev)
+    lqt = torch.nn.functional.interpolate(gt, scale_factor=1.0 / sc, mode="bicubic", antialias=True).clamp(0, 1)
     _, garr = net.flat_parameters()
 
     def grads_of(parts):
@@ -109,20 +115,20 @@ def test_bench_size_batch_is_the_union_of_its_halves():
         model.reset_current_log()
         outs = []
         for sl in parts:
-            model.feed_data({"lq": lq[sl], "gt": gt[sl]})
+            model.feed_data({"lq": lqt[sl], "gt": gt[sl]})
             model.optimize_parameters(1, 0, False)          # accumulate only: the weights stay where they are
             outs.append(model.output.clone())
         log = {k: float(v) for k, v in model.get_current_log().items()}
         torch.cuda.synchronize()
         return torch.cat(outs), garr.clone(), log
 
-    out16, g16, log16 = grads_of([slice(0, 16)])
-    out88, g88, log88 = grads_of([slice(0, 8), slice(8, 16)])
-    assert torch.equal(out16, out88), (out16 - out88).abs().max().item()
-    for k in log16:
+    out_f, g_f, log_f = grads_of([slice(0, batch)])
+    out_h, g_h, log_h = grads_of([slice(0, h), slice(h, batch)])
+    assert torch.equal(out_f, out_h), (out_f - out_h).abs().max().item()
+    for k in log_f:
         if k.startswith("l_g_"):
-            assert abs(log16[k] - log88[k]) <= 2e-6 * abs(log88[k]), (k, log16[k], log88[k])
-    half = g88.double() * 0.5
-    rel = ((g16.double() - half).norm() / half.norm()).item()
-    print(f"batch 16 vs 8 + 8: outputs identical, gradient rel-L2 {rel:.3e}, losses {log16}")
+            assert abs(log_f[k] - log_h[k]) <= 2e-6 * abs(log_h[k]), (k, log_f[k], log_h[k])
+    half = g_h.double() * 0.5
+    rel = ((g_f.double() - half).norm() / half.norm()).item()
+    print(f"{flags or 'esrgan'} batch {batch} vs {h} + {h}: outputs identical, gradient rel-L2 {rel:.3e}, losses {log_f}")
     assert rel < 2e-5, rel

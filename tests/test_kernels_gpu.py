@@ -187,10 +187,14 @@ def test_conv3x3_input_gradient_via_transposed_pack_and_mask(cuda, compute_name)
 
 
 @pytest.mark.parametrize("compute_name", ["f32", "bf16", "f16"])
-@pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 70, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 8)])
-def test_wgrad3x3(cuda, compute_name, shape):
+@pytest.mark.parametrize("impl", [0, 1, 2], ids=["auto", "reg", "ring"])
+@pytest.mark.parametrize("shape", [(2, 19, 37, 64, 32), (1, 8, 8, 96, 32), (1, 33, 70, 192, 64), (1, 16, 16, 8, 64), (2, 12, 40, 64, 8),
+                                   (1, 20, 40, 64, 96), (2, 16, 32, 96, 160), (1, 24, 32, 192, 96)])      # cout = 64 k + 32: half a last output group
+def test_wgrad3x3(cuda, compute_name, shape, impl):
     from trainner_redux_amd import _lib as L, ops
 
+    if impl and compute_name == "f32":
+        pytest.skip("one kernel family for fp32")
     compute, dt, rnd = ct(L, compute_name)
     n, h, w, cin, cout = shape
     g = torch.Generator().manual_seed(21 + cin)
@@ -204,11 +208,13 @@ def test_wgrad3x3(cuda, compute_name, shape):
     db = torch.full((cout,), 7.0, device=cuda)
     xd, gyd = nhwc(x).to(cuda, dt), nhwc(gy).to(cuda, dt)
     kw = dict(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), gy=ops.view(gyd), dw=dw, db=db, workspace=ws)
-    ops.wgrad3x3(**kw)
+    with ops.tuned(wgrad_impl=impl):
+        ops.wgrad3x3(**kw)
+        w1, b1 = dw.cpu().clone(), db.cpu().clone()
+        ops.wgrad3x3(**kw, accumulate=True)
     tol = 3e-6 if compute == L.F32 else 3e-6
-    assert rel_l2(dw.cpu(), ref_w) < tol, rel_l2(dw.cpu(), ref_w)
-    assert rel_l2(db.cpu(), ref_b) < 3e-6
-    ops.wgrad3x3(**kw, accumulate=True)
+    assert rel_l2(w1, ref_w) < tol, rel_l2(w1, ref_w)
+    assert rel_l2(b1, ref_b) < 3e-6
     assert rel_l2(dw.cpu(), 2 * ref_w) < tol
     assert rel_l2(db.cpu(), 2 * ref_b) < 3e-6
 

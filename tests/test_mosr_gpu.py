@@ -189,12 +189,13 @@ def test_mosr_fp32_matches_oracle(cuda, cfg):
         assert rel_l2(net.eval()(x.to(cuda)).cpu(), OM.forward(sd, x, hp)) < 1e-5
 
 
+@pytest.mark.parametrize("dim", [48, 64])      # 48: mosr_t (hid 72: generic conv epilogues); 64: mosr (hid 96 = 64 + 32: the 64-wide ring instances with half a last group)
 @pytest.mark.parametrize("dtype,policy", [(torch.bfloat16, "BF16_OPS"), (torch.float16, "F16_OPS")])
-def test_mosr_16bit_vs_policy_oracle(cuda, dtype, policy):
+def test_mosr_16bit_vs_policy_oracle(cuda, dtype, policy, dim):
     from oracle import mosr as OM
     from oracle import precision as OP
 
-    hp = OM.hparams(scale=2, n_block=3, dim=48)
+    hp = OM.hparams(scale=2, n_block=3, dim=dim)
     sd = OM.init_params(hp, 4, std=0.06, bias_std=0.02)
     x = torch.rand(2, 3, 24, 32, generator=torch.Generator().manual_seed(5))
     gy = torch.randn(2, 3, 48, 64, generator=torch.Generator().manual_seed(6)) / (2 * 3 * 48 * 64)

@@ -339,6 +339,7 @@ struct EpiTile {
     __amdgpu_buffer_rsrc_t r_out, r_out2, r_s1, r_s2;
     int c_out[2], c_out2[2], c_s1[2], c_s2[2];
     int y0, cs_out, cs_out2, cs_s1, cs_s2;      // first row of the tile; row pitches are w * cstride * esize (bytes)
+    int cg_left;                                // output channels from the group's first one to cout: tile t of a 64-wide group exists iff t * 32 < cg_left
     float slope, scale2, rs2;                   // act none: slope 1 ; no res2: v * 1 + 0 * res1
 };
 
@@ -358,6 +359,7 @@ __device__ __forceinline__ void epi_tile_setup(const ConvArgs& a, EpiTile<SIDE>&
     }
     const tr_view& s2v = (SIDE == 2 && a.res2.ptr) ? a.res2 : a.res1;
     T.y0 = y0;
+    T.cg_left = a.cout - cgbase;
     T.cs_out = a.w * a.out.cstride * ES_OUT;
     T.cs_out2 = (SIDE == 2 && a.out2.ptr) ? a.w * a.out2.cstride * 2 : 0;
     T.cs_s1 = SIDE == 1 ? a.w * a.mask.cstride * 2 : SIDE == 2 ? a.w * a.res1.cstride * 4 : 0;
@@ -448,13 +450,17 @@ __device__ __forceinline__ void epi_finish_fast(const ConvArgs& a, const EpiTile
         // offset may have its data registers overwritten by the VALU instruction behind it (observed on gfx950: the packed multiply of the out2
         // scaling changed one element of the fp32 `out` piece of the last lanes of each row; loads have no such exposure).  Out-of-range stays
         // out of range: OOB + any image offset is below 2^32 and above every num_records.
-        const unsigned vo = ((rowok && !(a.dbg & 4)) ? (unsigned)T.c_out[hf] : OOB);      // dbg 4 (TRAINNER_CONV_DBG, timing experiments): stores dropped by the bounds check
+        // The lane offsets were checked against cout for tile 0 of the group; a 64-wide group whose second tile lies past cout (cout = 64 k + 32: MoSR's
+        // 64 -> 96 input gradient) must drop that tile's stores too -- unmasked they landed on channels 0-31 of the NEXT pixel (found by the
+        // batch-halves property test, round 3; every earlier parity case had cout % 64 == 0 or took the generic body).
+        const bool tok = t * 32 < T.cg_left;
+        const unsigned vo = ((rowok && tok && !(a.dbg & 4)) ? (unsigned)T.c_out[hf] : OOB);      // dbg 4 (TRAINNER_CONV_DBG, timing experiments): stores dropped by the bounds check
         if constexpr (SIDE == 2) {
             const unsigned so = (unsigned)(oyc * T.cs_out + t * 128);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, T.r_out, (int)(vo + so), 0, TR_RING_STORE_AUX);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, T.r_out, (int)(vo + so + 16u), 0, TR_RING_STORE_AUX);
             const float sc = a.out2_scale;
-            const unsigned vo2 = (rowok ? (unsigned)T.c_out2[hf] : OOB) + (unsigned)(oyc * T.cs_out2 + t * 64);
+            const unsigned vo2 = ((rowok && tok) ? (unsigned)T.c_out2[hf] : OOB) + (unsigned)(oyc * T.cs_out2 + t * 64);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack2c<CT>(v[0] * sc, v[1] * sc), pack2c<CT>(v[2] * sc, v[3] * sc), pack2c<CT>(v[4] * sc, v[5] * sc), pack2c<CT>(v[6] * sc, v[7] * sc)},
                                                    T.r_out2, (int)vo2, 0, TR_RING_STORE_AUX);
         } else {
