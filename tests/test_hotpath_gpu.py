@@ -76,8 +76,11 @@ def test_fast_kernel_selection_matches_the_plain_paths(monkeypatch):
     assert rel < 5e-4 and cos > 0.999999, (rel, cos)        # measured 5.0e-5 / 1.00000000
 
 
-@pytest.mark.parametrize("flags,batch,lq", [("", 16, 256), ("--arch swinir_m", 8, 64), ("--arch span --compute f16", 64, 64), ("--arch mosr --compute f16", 64, 64)],
-                         ids=["configs1_esrgan", "configs3_swinir_m", "configs4_span_f16", "configs4_mosr_f16"])
+@pytest.mark.parametrize("flags,batch,lq", [("", 16, 256), ("--arch swinir_m", 8, 64), ("--arch span --compute f16", 64, 64), ("--arch mosr --compute f16", 64, 64),
+                                            ("--compute f16", 16, 256), ("--losses l1+perceptualfp16", 8, 256), ("--arch swinir_s", 8, 64), ("--arch span_s --compute f16", 64, 64),
+                                            ("--arch mosr_t --compute f16", 64, 64), ("--arch mosr", 64, 64), ("--arch span", 64, 64), ("--arch swinir_m --compute f16", 8, 64)],
+                         ids=["configs1_esrgan", "configs3_swinir_m", "configs4_span_f16", "configs4_mosr_f16", "esrgan_f16", "esrgan_perceptualfp16", "swinir_s", "span_s_f16",
+                              "mosr_t_f16", "mosr_bf16", "span_bf16", "swinir_m_f16"])
 def test_bench_size_batch_is_the_union_of_its_halves(flags, batch, lq):
     """Every bench workload at its FULL size (configs[1]: batch 16, 256 -> 1024, 23 blocks, L1 + fp32 perceptual, bf16; configs[3] SwinIR-M batch 8; configs[4]
     SPAN / MoSR 2x fp16 batch 64) -- sizes no oracle run reaches -- through a size-independent property: samples do not interact, so (a) the generator's
