@@ -135,3 +135,52 @@ def test_bench_size_batch_is_the_union_of_its_halves(flags, batch, lq):
     rel = ((g_f.double() - half).norm() / half.norm()).item()
     print(f"{flags or 'esrgan'} batch {batch} vs {h} + {h}: outputs identical, gradient rel-L2 {rel:.3e}, losses {log_f}")
     assert rel < 2e-5, rel
+
+
+@pytest.mark.parametrize("flags,batch,lq,bound", [("--arch mosr --compute f16", 64, 64, None), ("--arch span --compute f16", 64, 64, None), ("--arch swinir_m", 8, 64, None),
+                                                  ("--arch mosr", 64, 64, None)],
+                         ids=["mosr_f16", "span_f16", "swinir_m", "mosr_bf16"])
+def test_default_kernel_selection_matches_the_plain_kernels_at_bench_size(flags, batch, lq, bound):
+    """Differential check of the kernel families on the transformer / gated archs at their bench sizes: one accumulate-only step with the default selection
+    (LDS-DMA ring convs and weight gradients, LDS-DMA token GEMM with straight-line epilogues, 16-byte weight-gradient reduction) against the same step on the
+    register-staged kernels with the generic epilogues -- the families the small-tile oracle tests pin.  Same arithmetic in another summation order:
+    outputs agree to 16-bit rounding flips, parameter gradients to the cosine / rel-L2 printed below."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import bench
+    from trainner_redux_amd import ops
+    from trainner_redux_amd.models import build_model
+
+    argv = sys.argv
+    sys.argv = ["bench.py", *flags.split(), "--batch", str(batch), "--lq", str(lq)]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    torch.manual_seed(1024)
+    model = build_model(bench.make_opt(args))
+    net = model.net_g
+    if hasattr(net, "drop_path_rate"):
+        net.drop_path_rate = 0.0
+    sc = args.scale
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(batch, 3, sc * lq, sc * lq, generator=g).cuda()
+    lqt = torch.nn.functional.interpolate(gt, scale_factor=1.0 / sc, mode="bicubic", antialias=True).clamp(0, 1)
+    _, garr = net.flat_parameters()
+
+    def run(**tune):
+        garr.zero_()
+        model.reset_current_log()
+        with ops.tuned(**tune):
+            model.feed_data({"lq": lqt, "gt": gt})
+            model.optimize_parameters(1, 0, False)
+        torch.cuda.synchronize()
+        return model.output.float().clone(), garr.double().clone(), float(model.get_current_log()["l_g_total"])
+
+    out_d, g_d, l_d = run()
+    out_p, g_p, l_p = run(conv_impl=1, wgrad_impl=1, wgrad_multi=0, linear_impl=1, linear_epilogue=1, wgrad_reduce=1)
+    e_out = ((out_d - out_p).double().norm() / out_p.double().norm()).item()
+    rel = ((g_d - g_p).norm() / g_p.norm()).item()
+    cos = (torch.dot(g_d, g_p) / (g_d.norm() * g_p.norm())).item()
+    print(f"{flags}: output rel-L2 {e_out:.3e}, loss {l_d:.7f} vs {l_p:.7f}, gradient rel-L2 {rel:.3e}, cosine {cos:.7f}")
+    assert e_out < 2e-3 and abs(l_d - l_p) <= 1e-4 * abs(l_p) and cos > 0.9995 and rel < 3e-2, (e_out, l_d, l_p, rel, cos)
