@@ -1,0 +1,241 @@
+"""Seeded random sweep of `tr_conv3x3` against `F.conv2d` (CPU, fp32, on the same rounded operands) under the AUTOMATIC kernel selection -- whatever family
+(register-staged, LDS-DMA ring with its fast / generic epilogue forms, token GEMM) the library picks for a shape must agree with the plain convolution.
+
+Why: every hand-written case list so far shared the hot path's habits (cout a multiple of the output-group width, slices of 192-channel buffers).  The
+round-3 bug -- the 64-wide ring instances stored the absent second tile of a half-filled last group into the next pixel when cout = 64 k + 32 -- sat in
+exactly the shapes nobody had listed.  This sweep draws shapes nobody chose: channel counts 8 .. 256 in steps of 8, ragged h / w, input and output views
+that are slices of wider buffers at random offsets (the bytes around the output slice must survive), and each epilogue form of the header's contract
+(include/trainner_hip.h: bias, activation, per-sample scale, one or two residuals, sign mask, second output).
+
+Tolerances as tests/test_conv_ring_gpu.py: fp32 outputs rel-L2 <= 3e-6; 16-bit outputs <= 1e-3 against the reference rounded the same way with >= 99 % of the
+elements identical."""
+import math
+import random
+
+import pytest
+import torch
+from torch.nn import functional as F
+
+pytestmark = pytest.mark.gpu
+
+CH = [8, 16, 24, 32, 40, 48, 64, 72, 96, 104, 128, 160, 192, 224, 256]
+FORMS = ["plain", "bias_lrelu", "relu", "mask", "res1", "res2_out2", "scale_res1", "mask_out2"]
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
+def _case(seed):
+    r = random.Random(seed)
+    compute = r.choice(["bf16", "bf16", "f16", "f32"])
+    n, h, w = r.randint(1, 3), r.randint(3, 44), r.randint(3, 76)
+    cin, cout = r.choice(CH), r.choice(CH)
+    if compute == "f32":                                  # fp32 MFMA is 16x slower and the CPU reference dominates: keep the products small
+        cin, cout = min(cin, 96), min(cout, 96)
+    form = r.choice(FORMS)
+    in_slack, out_slack = r.choice([0, 0, 8, 32]), r.choice([0, 0, 8, 32, 64])
+    in_off = r.choice([0, 8]) if in_slack >= 8 else 0
+    out_off = r.choice([0, 8, 16, 32]) if out_slack >= 32 else (r.choice([0, 8]) if out_slack >= 8 else 0)
+    out_off = min(out_off, out_slack)
+    return dict(seed=seed, compute=compute, n=n, h=h, w=w, cin=cin, cout=cout, form=form, in_slack=in_slack, in_off=in_off, out_slack=out_slack, out_off=out_off)
+
+
+@pytest.mark.parametrize("seed", range(160))
+def test_conv3x3_random_shape_matches_conv2d(cuda, seed):
+    from trainner_redux_amd import _lib as L, ops
+
+    c = _case(seed)
+    compute, dt = {"bf16": (L.BF16, torch.bfloat16), "f16": (L.F16, torch.float16), "f32": (L.F32, torch.float32)}[c["compute"]]
+    rnd = (lambda t: t.to(dt).to(torch.float32))
+    n, h, w, cin, cout, form = c["n"], c["h"], c["w"], c["cin"], c["cout"], c["form"]
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = rnd(torch.randn(n, cin, h, w, generator=g))
+    wt = rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g)
+    pre = rnd(torch.randn(n, cout, h, w, generator=g))
+    r1, r2 = torch.randn(n, cout, h, w, generator=g), torch.randn(n, cout, h, w, generator=g)
+    ss = torch.rand(n, generator=g) + 0.5
+
+    v = F.conv2d(x, wt, None if form in ("plain", "mask", "mask_out2") else b, padding=1)
+    kw, out32, second = {}, False, False
+    if form == "bias_lrelu":
+        v = F.leaky_relu(v, 0.2); kw = dict(act=L.ACT_LRELU, slope=0.2)
+    elif form == "relu":
+        v = F.relu(v); kw = dict(act=L.ACT_RELU)
+    elif form in ("mask", "mask_out2"):
+        v = v * torch.where(pre > 0, 1.0, 0.2); second = form == "mask_out2"
+    elif form == "res1":
+        v = v * 0.2 + r1; out32 = True
+    elif form == "res2_out2":
+        v = (v * 0.2 + r1) * 0.2 + 0.7 * r2; out32, second = True, True
+    elif form == "scale_res1":
+        v = v * ss.view(n, 1, 1, 1) + r1; out32 = True
+    ref = v
+
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()        # noqa: E731
+    xin = torch.randn(n, h, w, cin + c["in_slack"], generator=g)
+    xin[..., c["in_off"]:c["in_off"] + cin] = nhwc(x)
+    xd = xin.to(cuda, dt)
+    wbuf = torch.zeros(ops.packed_bytes(cin, cout, compute), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda); plan.add(wt.to(cuda), wbuf, cin, cout, compute); plan.run()
+    odt = torch.float32 if (out32 or compute == L.F32) else dt
+    out = torch.full((n, h, w, cout + c["out_slack"]), 3.0, dtype=odt, device=cuda)
+    out2 = torch.full((n, h, w, cout + 8), 5.0, dtype=dt, device=cuda)
+    bias = None if form in ("plain", "mask", "mask_out2") else b.to(cuda)
+    if form in ("mask", "mask_out2"):
+        kw = dict(mask=ops.view(nhwc(pre).to(cuda, dt)), mask_slope=0.2)
+    if form in ("res1", "res2_out2", "scale_res1"):
+        r1d = nhwc(r1).to(cuda)
+        kw = dict(res1=ops.view(r1d), scale1=1.0 if form == "scale_res1" else 0.2)
+    if form == "res2_out2":
+        r2d = nhwc(r2).to(cuda)
+        kw.update(res2=ops.view(r2d), scale2=0.2, res2_scale=0.7)
+    if form == "scale_res1":
+        kw.update(sample_scale=ss.to(cuda))
+    if second:
+        kw.update(out2=ops.view(out2, 0, cout), out2_scale=0.5)
+    keep = [v_ for v_ in kw.values() if not isinstance(v_, (int, float))]      # views hold raw pointers: keep their tensors alive   # noqa: F841
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd, c["in_off"], cin), out=ops.view(out, c["out_off"], cout), wpacked=wbuf,
+                bias=bias, **kw)
+    fam, inst = ops.last_conv_family(), ops.tune_get("last_conv_instance")
+    got = out.float().cpu()
+    o0 = c["out_off"]
+    what = (c, fam, inst)
+
+    def check(got_nchw, ref_t, dtype_out):
+        if dtype_out == torch.float32:
+            e = rel_l2(got_nchw, ref_t)
+            assert e < (3e-6 if compute != L.F32 else 3e-6), (what, e)
+        else:
+            refr = ref_t.to(dtype_out).to(torch.float32)
+            e, same = rel_l2(got_nchw, refr), (got_nchw == refr).float().mean().item()
+            assert e < 1e-3 and same > 0.99, (what, e, same)
+
+    check(got[..., o0:o0 + cout].permute(0, 3, 1, 2), ref, odt)
+    assert torch.all(got[..., :o0] == 3.0) and torch.all(got[..., o0 + cout:] == 3.0), (what, "bytes around the output slice were written")
+    if second:
+        g2 = out2.float().cpu()
+        check(g2[..., :cout].permute(0, 3, 1, 2), ref * 0.5, dt)
+        assert torch.all(g2[..., cout:] == 5.0), (what, "bytes behind the second output were written")
+
+
+LIN_FORMS = ["plain_cd", "plain_f32", "res_f32", "gelu_cd", "gelu_mask_cd", "scale_res_f32"]
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_token_gemm_random_shape_matches_linear(cuda, seed):
+    """ksize 1 on a 32-wide token grid (nn.Linear over tokens, drct_arch.py:64-66,166-168): the LDS-DMA token GEMM with its straight-line epilogue forms,
+    the register-staged one and the conv-tiled fallback, whichever the library picks, against `x @ W^T + b` (+ exact-erf GELU / GELU' / residual / DropPath scale)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    r = random.Random(5000 + seed)
+    cname = r.choice(["bf16", "bf16", "f16", "f32"])
+    compute, dt = {"bf16": (L.BF16, torch.bfloat16), "f16": (L.F16, torch.float16), "f32": (L.F32, torch.float32)}[cname]
+    rnd = (lambda t: t.to(dt).to(torch.float32))
+    n, h, w = r.randint(1, 3), r.randint(1, 40), 32
+    cin = r.choice([32, 64, 96, 128, 160, 192, 256, 384, 544])
+    cout = r.choice([32, 48, 60, 64, 96, 120, 180, 192, 256, 360, 540])
+    form = r.choice(LIN_FORMS)
+    cs_in = cin + r.choice([0, 0, 32])
+    cop = (cout + 31) // 32 * 32 + r.choice([0, 32])
+    g = torch.Generator().manual_seed(7000 + seed)
+    x = rnd(torch.randn(n, h, w, cin, generator=g))
+    wt = rnd(torch.randn(cout, cin, generator=g) / math.sqrt(cin))
+    b = torch.randn(cout, generator=g)
+    pre_m = rnd(torch.randn(n, h, w, cout, generator=g))
+    res = torch.randn(n, h, w, cout, generator=g)
+    ss = torch.rand(n, generator=g) + 0.5
+    v = x @ wt.t() + b
+    pre = v
+    out32 = form in ("plain_f32", "res_f32", "scale_res_f32") or compute == L.F32
+    kw = {}
+    if form == "res_f32":
+        v = v + res
+    elif form == "scale_res_f32":
+        v = v * ss.view(n, 1, 1, 1) + res
+    elif form == "gelu_cd":
+        v = F.gelu(v)
+    elif form == "gelu_mask_cd":
+        m = pre_m.double()
+        v = v * (0.5 * (1 + torch.erf(m / math.sqrt(2))) + m * torch.exp(-0.5 * m * m) / math.sqrt(2 * math.pi)).float()
+    xin = torch.randn(n, h, w, cs_in, generator=g)
+    xin[..., :cin] = x
+    xd = xin.to(cuda, dt)
+    wbuf = torch.zeros(ops.packed_bytes(cin, cout, compute, 1), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda); plan.add(wt.to(cuda), wbuf, cin, cout, compute); plan.run()
+    odt = torch.float32 if out32 else dt
+    out = torch.full((n, h, w, cop), 3.0, dtype=odt, device=cuda)
+    out2 = torch.full((n, h, w, cop), 5.0, dtype=dt, device=cuda)
+    resd, md, ssd = res.to(cuda), pre_m.to(cuda, dt), ss.to(cuda)
+    if form in ("res_f32", "scale_res_f32"):
+        kw.update(res1=ops.view(resd))
+    if form == "scale_res_f32":
+        kw.update(sample_scale=ssd)
+    if form == "gelu_cd":
+        kw.update(act=L.ACT_GELU, out2=ops.view(out2, 0, cout))
+    if form == "gelu_mask_cd":
+        kw.update(mask=ops.view(md), mask_mode=1)
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd, 0, cin), out=ops.view(out, 0, cout), wpacked=wbuf, bias=b.to(cuda), ksize=1, **kw)
+    what = (seed, cname, n, h, cin, cout, form, ops.last_conv_family())
+    got = out.float().cpu()
+
+    def check(got_t, ref_t, dtype_out):
+        if dtype_out == torch.float32:
+            e = rel_l2(got_t, ref_t)
+            assert e < 3e-6, (what, e)
+        else:
+            refr = ref_t.to(dtype_out).to(torch.float32)
+            e, same = rel_l2(got_t, refr), (got_t == refr).float().mean().item()
+            assert e < 1e-3 and same > 0.985, (what, e, same)        # the 16-bit forms' GELU is the rcp / exp form (4e-7 absolute): a few more 1-ulp flips
+
+    check(got[..., :cout], v, odt)
+    assert torch.all(got[..., cout:] == 3.0) or torch.all(got[..., (cout + 3) // 4 * 4:] == 3.0), (what, "bytes behind the output were written")
+    if form == "gelu_cd":
+        check(out2.float().cpu()[..., :cout], pre, dt)
+
+
+@pytest.mark.parametrize("seed", range(70))
+def test_wgrad_random_shape_matches_conv2d_weight(cuda, seed):
+    """`tr_wgrad3x3` (3x3 and ksize 1) on random shapes and channel slices under the automatic selection (register-staged, ring, split-K token kernel; 4- or
+    16-byte second stage): dW against `torch.nn.grad.conv2d_weight`, db against the plain sum, written once and accumulated once."""
+    from trainner_redux_amd import _lib as L, ops
+
+    r = random.Random(9000 + seed)
+    cname = r.choice(["bf16", "bf16", "f16", "f32"])
+    compute, dt = {"bf16": (L.BF16, torch.bfloat16), "f16": (L.F16, torch.float16), "f32": (L.F32, torch.float32)}[cname]
+    rnd = (lambda t: t.to(dt).to(torch.float32))
+    ks = r.choice([3, 3, 1])
+    n = r.randint(1, 3)
+    h, w = (r.randint(1, 24), 32) if ks == 1 else (r.randint(3, 36), r.randint(3, 70))
+    cin, cout = r.choice(CH + [180, 360]), r.choice(CH + [180, 544])
+    if cname == "f32":
+        cin, cout = min(cin, 96), min(cout, 96)
+    if ks == 1 and cin == 180:
+        cin = 192
+    g = torch.Generator().manual_seed(11000 + seed)
+    x = rnd(torch.randn(n, cin, h, w, generator=g))
+    gy = rnd(torch.randn(n, cout, h, w, generator=g))
+    ref_w = torch.nn.grad.conv2d_weight(x, (cout, cin, ks, ks), gy, padding=ks // 2)
+    ref_b = gy.sum(dim=(0, 2, 3))
+    si, so = r.choice([0, 8, 32]), r.choice([0, 8, 32])
+    oi, oo = (r.choice([0, 8]) if si else 0), (r.choice([0, 8]) if so else 0)
+    cpi, cpo = (cin + 7) // 8 * 8, (cout + 7) // 8 * 8
+    xin = torch.randn(n, h, w, cpi + si, generator=g); xin[..., oi:oi + cin] = x.permute(0, 2, 3, 1)
+    gin = torch.randn(n, h, w, cpo + so, generator=g); gin[..., oo:oo + cout] = gy.permute(0, 2, 3, 1)
+    if cpi != cin:
+        xin[..., oi + cin:oi + cpi] = 0                   # the view is 8-channel granular: the pad channels belong to it
+    if cpo != cout:
+        gin[..., oo + cout:oo + cpo] = 0
+    xd, gd = xin.to(cuda, dt), gin.to(cuda, dt)
+    ws = torch.empty(ops.wgrad_workspace_bytes(n, h, w, cin, cout, ks) // 4 + 16, dtype=torch.float32, device=cuda)
+    dw = torch.full((cout, cin, ks, ks) if ks == 3 else (cout, cin), 7.0, device=cuda)
+    db = torch.full((cout,), 7.0, device=cuda)
+    kw = dict(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd, oi, cpi), gy=ops.view(gd, oo, cpo), dw=dw, db=db, workspace=ws, ksize=ks)
+    ops.wgrad3x3(**kw)
+    w1, b1 = dw.cpu().clone(), db.cpu().clone()
+    ops.wgrad3x3(**kw, accumulate=True)
+    what = (seed, cname, ks, n, h, w, cin, cout, si, oi, so, oo)
+    assert rel_l2(w1.view_as(ref_w), ref_w) < 4e-6, (what, rel_l2(w1.view_as(ref_w), ref_w))
+    assert rel_l2(b1, ref_b) < 4e-6, (what, rel_l2(b1, ref_b))
+    assert rel_l2(dw.cpu().view_as(ref_w), 2 * ref_w) < 4e-6 and rel_l2(db.cpu(), 2 * ref_b) < 4e-6, what
