@@ -239,3 +239,63 @@ def test_wgrad_random_shape_matches_conv2d_weight(cuda, seed):
     assert rel_l2(w1.view_as(ref_w), ref_w) < 4e-6, (what, rel_l2(w1.view_as(ref_w), ref_w))
     assert rel_l2(b1, ref_b) < 4e-6, (what, rel_l2(b1, ref_b))
     assert rel_l2(dw.cpu().view_as(ref_w), 2 * ref_w) < 4e-6 and rel_l2(db.cpu(), 2 * ref_b) < 4e-6, what
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_conv3x3_many_tiles_per_workgroup_ring_vs_register_staged(cuda, seed):
+    """The sweeps above run a tile or two per workgroup.  The persistent kernels' cross-tile machinery (the halo stream running into the next tile during
+    the epilogue, LDS strips aliasing a consumed ring stage, pipelined epilogue units hooked into the next tile's MFMAs) only runs when a workgroup walks
+    SEVERAL tiles: 2^18 .. 2^19 pixels here (2 .. 8 tiles per workgroup).  No CPU reference at that size: the ring kernel is compared with the
+    register-staged kernel, which the small-shape sweeps pin to F.conv2d -- same products, same K order, so fp32 outputs agree to 2e-6 and 16-bit
+    outputs are identical on >= 99.8 % of the elements.  Ragged right / bottom edges, random channel slices, every epilogue form."""
+    from trainner_redux_amd import _lib as L, ops
+
+    r = random.Random(13000 + seed)
+    cname = r.choice(["bf16", "f16"])
+    compute, dt = (L.BF16, torch.bfloat16) if cname == "bf16" else (L.F16, torch.float16)
+    n = r.choice([2, 4, 8])
+    h = r.choice([128, 200, 250, 256]); w = (1 << r.choice([18, 19])) // (n * h) + r.choice([0, 3, 17])
+    cin = r.choice([32, 64, 96, 128, 160, 192]); cout = r.choice([32, 64, 96, 128, 160, 48, 24])
+    form = r.choice([f for f in FORMS if f != "scale_res1"])          # a per-sample scale is served by the register-staged kernel only
+    g = torch.Generator(device="cuda").manual_seed(17000 + seed)
+    x = torch.randn(n, h, w, cin + 32, device=cuda, generator=g).to(dt)
+    wt = (torch.randn(cout, cin, 3, 3, device=cuda, generator=g) / math.sqrt(cin * 9))
+    b = torch.randn(cout, device=cuda, generator=g)
+    pre = torch.randn(n, h, w, cout, device=cuda, generator=g).to(dt)
+    r1, r2 = torch.randn(n, h, w, cout, device=cuda, generator=g), torch.randn(n, h, w, cout, device=cuda, generator=g)
+    ss = torch.rand(n, device=cuda, generator=g) + 0.5
+    wbuf = torch.zeros(ops.packed_bytes(cin, cout, compute), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda); plan.add(wt, wbuf, cin, cout, compute); plan.run()
+    out32 = form in ("res1", "res2_out2", "scale_res1")
+    second = form in ("res2_out2", "mask_out2")
+    kw = {}
+    if form == "bias_lrelu": kw = dict(act=L.ACT_LRELU, slope=0.2)
+    if form == "relu": kw = dict(act=L.ACT_RELU)
+    if form in ("mask", "mask_out2"): kw = dict(mask=ops.view(pre), mask_slope=0.2)
+    if out32: kw = dict(res1=ops.view(r1), scale1=1.0 if form == "scale_res1" else 0.2)
+    if form == "res2_out2": kw.update(res2=ops.view(r2), scale2=0.2, res2_scale=0.7)
+    if form == "scale_res1": kw.update(sample_scale=ss)
+    bias = None if form in ("plain", "mask", "mask_out2") else b
+    res = {}
+    for impl in (1, 2):
+        out = torch.full((n, h, w, cout + 32), 3.0, dtype=torch.float32 if out32 else dt, device=cuda)
+        out2 = torch.full((n, h, w, cout + 8), 5.0, dtype=dt, device=cuda)
+        k2 = dict(kw, out2=ops.view(out2, 0, cout), out2_scale=0.5) if second else kw
+        with ops.tuned(conv_impl=impl):
+            ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(x, 8, cin), out=ops.view(out, 16, cout), wpacked=wbuf, bias=bias, **k2)
+        res[impl] = (out, out2, ops.last_conv_family(), ops.tune_get("last_conv_instance"))
+    (o1, p1, f1, _), (o2, p2, f2, inst) = res[1], res[2]
+    what = (seed, cname, n, h, w, cin, cout, form, f1, f2, inst)
+    assert f1 == "reg", what
+    if f2 != "ring":
+        pytest.skip(f"not ring-eligible: {what}")
+    assert torch.all(o2[..., :16] == 3.0) and torch.all(o2[..., 16 + cout:] == 3.0) and torch.all(p2[..., cout:] == 5.0), (what, "bytes around the outputs were written")
+    a, bb = o2[..., 16:16 + cout].float(), o1[..., 16:16 + cout].float()
+    if out32:
+        assert rel_l2(a, bb) < 2e-6, (what, rel_l2(a, bb))
+    else:
+        same = (a == bb).float().mean().item()
+        assert same > 0.998 and rel_l2(a, bb) < 1e-3, (what, same, rel_l2(a, bb))
+    if second:
+        same2 = (p2[..., :cout] == p1[..., :cout]).float().mean().item()
+        assert same2 > 0.998, (what, same2)
