@@ -299,3 +299,99 @@ def test_conv3x3_many_tiles_per_workgroup_ring_vs_register_staged(cuda, seed):
     if second:
         same2 = (p2[..., :cout] == p1[..., :cout]).float().mean().item()
         assert same2 > 0.998, (what, same2)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_layernorm_random_shape_matches_torch(cuda, seed):
+    """`tr_layernorm` / `tr_layernorm_bwd` (16-byte and 4-byte kernels, whichever the shape allows) on random token counts (not multiples of the 8 tokens a wave
+    takes), channel counts 4 .. 256, padded channel strides, 16-bit or fp32 gradient / output views, with and without the folded residual."""
+    from trainner_redux_amd import ops
+
+    r = random.Random(21000 + seed)
+    c = r.choice([4, 8, 20, 36, 48, 60, 64, 90, 96, 128, 180, 192, 200, 256, 30, 45])
+    cp = c + r.choice([0, 0, 4, 12, 32]) if c % 4 == 0 else c + r.choice([0, 3])
+    ntok = r.choice([1, 5, 8, 31, 64, 257, 1000, 4099, 20000])
+    ydt = r.choice([torch.float32, torch.bfloat16, torch.float16])
+    gdt = r.choice([torch.float32, torch.bfloat16])
+    with_res = r.random() < 0.6
+    eps = r.choice([1e-5, 1e-6])
+    g = torch.Generator().manual_seed(23000 + seed)
+    x = torch.randn(ntok, c, generator=g) * 2 + 0.5
+    gam, bet = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    gy = torch.randn(ntok, c, generator=g).to(gdt).float()
+    res = torch.randn(ntok, c, generator=g)
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (c,), gr, br, eps)
+    y.backward(gy)
+    xd = torch.randn(ntok, cp, generator=g).to(cuda)
+    xd[:, :c] = x.to(cuda)
+    yd = torch.full((ntok, cp), 7.0, dtype=ydt, device=cuda)
+    mean, rstd = torch.empty(ntok, device=cuda), torch.empty(ntok, device=cuda)
+    gd, bd = gam.to(cuda), bet.to(cuda)
+    ops.layernorm(ops.view(xd, 0, c), ops.view(yd, 0, c), ntok, c, gd, bd, eps, mean, rstd)
+    what = (seed, c, cp, ntok, ydt, gdt, with_res)
+    tol = 3e-6 if ydt == torch.float32 else (4e-3 if ydt == torch.bfloat16 else 6e-4)
+    assert rel_l2(yd[:, :c].float().cpu(), y.detach()) < tol, (what, rel_l2(yd[:, :c].float().cpu(), y.detach()))
+    assert torch.all(yd[:, c:] == 7.0), (what, "bytes behind the output view were written")
+    assert rel_l2(mean.cpu(), x.mean(1)) < 1e-5 or x.mean(1).abs().max() < 1e-3
+    gyd = torch.zeros(ntok, cp, dtype=gdt, device=cuda)
+    gyd[:, :c] = gy.to(cuda, gdt)
+    resd = torch.randn(ntok, cp, generator=g).to(cuda)
+    resd[:, :c] = res.to(cuda)
+    dx = torch.full((ntok, cp), 9.0, device=cuda)
+    dgam, dbet = torch.full((c,), 2.0, device=cuda), torch.full((c,), 2.0, device=cuda)
+    ws = torch.empty(ops.layernorm_bwd_workspace_bytes(c) // 4, device=cuda)
+    ops.layernorm_bwd(ops.view(gyd, 0, c), ops.view(xd, 0, c), ntok, c, gd, mean, rstd, ops.view(resd, 0, c) if with_res else ops.NULL_VIEW, ops.view(dx, 0, c), dgam, dbet,
+                      ws)
+    ref_dx = xr.grad + (res if with_res else 0)
+    assert rel_l2(dx[:, :c].cpu(), ref_dx) < 5e-6, (what, rel_l2(dx[:, :c].cpu(), ref_dx))
+    assert torch.all(dx[:, c:] == 9.0), (what, "bytes behind dx were written")
+    assert rel_l2(dgam.cpu() - 2.0, gr.grad) < 2e-5 and rel_l2(dbet.cpu() - 2.0, br.grad) < 2e-5, (what, rel_l2(dgam.cpu() - 2.0, gr.grad), rel_l2(dbet.cpu() - 2.0, br.grad))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_winograd43_random_shape_matches_conv2d(cuda, seed):
+    """The fp32 Winograd F(4x4,3x3) kernel of the VGG head on random eligible shapes (h, w multiples of 4, cin > 32 in steps of 8, cout in steps of 64), several
+    tiles per persistent workgroup in some, all three epilogue forms (bias + ReLU, bias + ReLU + fused 2x2 max-pool output, input-gradient form with the
+    ReLU-derivative mask), against fp64 `F.conv2d` / `conv_transpose2d`: 1e-5 (measured 2e-6 per layer)."""
+    from trainner_redux_amd import _lib as L, ops
+
+    r = random.Random(25000 + seed)
+    n = r.randint(1, 3)
+    h, w = 4 * r.randint(1, 40), 4 * r.randint(1, 60)
+    cin, cout = r.choice([40, 64, 72, 128, 192, 256]), r.choice([64, 128, 192, 256])
+    form = r.choice(["relu", "pool", "mask"])
+    if not ops.winograd43_eligible(cin, cout, h, w):
+        pytest.skip("not eligible")
+    g = torch.Generator().manual_seed(27000 + seed)
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g, dtype=torch.float64))
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) * math.sqrt(2 / (cin * 9))
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    xd = x.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+    what = (seed, n, h, w, cin, cout, form)
+    if form in ("relu", "pool"):
+        ref = torch.relu(F.conv2d(x, wt, b, padding=1))
+        out = torch.full((n, h, w, cout + 4), 3.0, device=cuda)
+        pooled = torch.full((n, h // 2, w // 2, cout + 4), 5.0, device=cuda)
+        U = ops.pack_winograd43(wt.float().to(cuda))
+        kw = dict(out2=ops.view(pooled, 0, cout)) if form == "pool" else {}
+        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=L.F32_WINOGRAD43, inp=ops.view(xd), out=ops.view(out, 4, cout), wpacked=U, bias=b.float().to(cuda),
+                    act=L.ACT_RELU, **kw)
+        assert rel_l2(out[..., 4:].permute(0, 3, 1, 2).cpu(), ref) < 1e-5, what
+        assert torch.all(out[..., :4] == 3.0), what
+        if form == "pool":
+            assert rel_l2(pooled[..., :cout].permute(0, 3, 1, 2).cpu(), F.max_pool2d(ref, 2, 2)) < 1e-5 and torch.all(pooled[..., cout:] == 5.0), what
+    else:
+        if cin % 64:
+            pytest.skip("the input-gradient form writes cin channels: 64-wide groups")
+        gy = torch.randn(n, cout, h, w, generator=g, dtype=torch.float64)
+        m = torch.randn(n, cin, h, w, generator=g, dtype=torch.float64)
+        ref = F.conv_transpose2d(gy, wt, padding=1) * (m > 0)
+        if not ops.winograd43_eligible(cout, cin, h, w):
+            pytest.skip("not eligible")
+        Ut = ops.pack_winograd43(wt.float().to(cuda), transpose=True)
+        gin = torch.full((n, h, w, cin), 3.0, device=cuda)
+        gyd = gy.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+        md = m.float().permute(0, 2, 3, 1).contiguous().to(cuda)
+        ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.F32_WINOGRAD43, inp=ops.view(gyd), out=ops.view(gin), wpacked=Ut, mask=ops.view(md), mask_slope=0.0)
+        assert rel_l2(gin.permute(0, 3, 1, 2).cpu(), ref) < 1e-5, what
