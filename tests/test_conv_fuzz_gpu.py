@@ -395,3 +395,62 @@ def test_winograd43_random_shape_matches_conv2d(cuda, seed):
         md = m.float().permute(0, 2, 3, 1).contiguous().to(cuda)
         ops.conv3x3(n=n, h=h, w=w, cin=cout, cout=cin, compute=L.F32_WINOGRAD43, inp=ops.view(gyd), out=ops.view(gin), wpacked=Ut, mask=ops.view(md), mask_slope=0.0)
         assert rel_l2(gin.permute(0, 3, 1, 2).cpu(), ref) < 1e-5, what
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_conv_input_modes_random_shape(cuda, seed):
+    """The input modes of `tr_conv3x3` on random shapes: nearest-2x fused into the load (nn.Upsample -> conv, scunet_aaf6aa_arch.py:371-377), replicate padding
+    (VGG conv1_1, perceptual_fp16_loss.py:262-274), the 'full' correlation over an (h-2) x (w-2) input and the padding-free 'valid' form over (h+2) x (w+2)
+    (SPAN's Conv3XC and its input gradient, span_arch.py:134-141,199-204), ksize 3 and 1 where the mode allows it."""
+    from trainner_redux_amd import _lib as L, ops
+
+    r = random.Random(31000 + seed)
+    cname = r.choice(["bf16", "f16", "f32"])
+    compute, dt = {"bf16": (L.BF16, torch.bfloat16), "f16": (L.F16, torch.float16), "f32": (L.F32, torch.float32)}[cname]
+    rnd = (lambda t: t.to(dt).to(torch.float32))
+    mode = r.choice(["nearest2x", "replicate", "full", "valid", "valid_k1", "full_k1"])
+    n = r.randint(1, 3)
+    h, w = r.randint(3, 40), r.randint(3, 70)
+    if mode == "nearest2x":
+        h, w = 2 * r.randint(2, 20), 2 * r.randint(2, 35)
+    cin, cout = r.choice([8, 16, 32, 48, 56, 64, 96, 104, 128]), r.choice([8, 16, 32, 48, 56, 64, 96, 104, 128])
+    if cname == "f32":
+        cin, cout = min(cin, 64), min(cout, 64)
+    ks = 1 if mode.endswith("_k1") else 3
+    lrelu = r.random() < 0.5
+    g = torch.Generator().manual_seed(33000 + seed)
+    ih, iw = {"nearest2x": (h // 2, w // 2), "replicate": (h, w), "full": (h - 2, w - 2), "valid": (h + 2, w + 2), "valid_k1": (h + 2, w + 2), "full_k1": (h - 2, w - 2)}[mode]
+    x = rnd(torch.randn(n, cin, ih, iw, generator=g))
+    wt = rnd(torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * ks * ks))
+    b = torch.randn(cout, generator=g)
+    if mode == "nearest2x":
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    elif mode == "replicate":
+        ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="replicate"), wt, b)
+    elif mode == "full":
+        ref = F.conv2d(x, wt, b, padding=2)
+    elif mode == "valid":
+        ref = F.conv2d(x, wt, b)
+    elif mode == "valid_k1":
+        ref = F.conv2d(x[:, :, 1:-1, 1:-1], wt, b)
+    else:   # full_k1: out(y, x) = W in(y - 1, x - 1), zeros outside -- the bias lands on the border too (Conv3XC's first 1x1 over the padded grid)
+        ref = F.conv2d(F.pad(x, (1, 1, 1, 1)), wt, b)
+    if lrelu:
+        ref = F.leaky_relu(ref, 0.2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda, dt)
+    wbuf = torch.zeros(ops.packed_bytes(cin, cout, compute, ks), dtype=torch.uint8, device=cuda)
+    plan = ops.PackPlan(cuda); plan.add(wt.to(cuda) if ks == 3 else wt.reshape(cout, cin).to(cuda), wbuf, cin, cout, compute); plan.run()
+    out = torch.full((n, h, w, cout + 8), 3.0, dtype=dt, device=cuda)
+    im = {"nearest2x": L.IN_NEAREST2X, "replicate": L.IN_DIRECT, "full": L.IN_FULL, "valid": L.IN_VALID, "valid_k1": L.IN_VALID, "full_k1": L.IN_FULL}[mode]
+    ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out, 0, cout), wpacked=wbuf, bias=b.to(cuda), in_mode=im,
+                pad_mode=L.PAD_REPLICATE if mode == "replicate" else L.PAD_ZEROS, ksize=ks, **(dict(act=L.ACT_LRELU, slope=0.2) if lrelu else {}))
+    what = (seed, cname, mode, n, h, w, cin, cout, lrelu, ops.last_conv_family())
+    got = out.float().cpu()
+    assert tuple(ref.shape) == (n, cout, h, w), (what, ref.shape)
+    if dt == torch.float32:
+        assert rel_l2(got[..., :cout].permute(0, 3, 1, 2), ref) < 3e-6, (what, rel_l2(got[..., :cout].permute(0, 3, 1, 2), ref))
+    else:
+        refr = ref.to(dt).float()
+        e, same = rel_l2(got[..., :cout].permute(0, 3, 1, 2), refr), (got[..., :cout].permute(0, 3, 1, 2) == refr).float().mean().item()
+        assert e < 1e-3 and same > 0.99, (what, e, same)
+    assert torch.all(got[..., cout:] == 3.0), (what, "bytes behind the output were written")
