@@ -20,5 +20,13 @@ for flags, steps, warm in RUNS:
     rf.pop("all", None)
     out.append({"flags": flags, "workload": d["config"]["workload"], "value": round(d["value"], 1), "unit": d["unit"], "ms_per_step": round(d["ms_per_step"], 2),
                 "dtype": d["dtype"], "roofline": rf})
-    print(flags, "->", out[-1]["value"], d["unit"], out[-1]["ms_per_step"], "ms/step", flush=True)
+    # the same run without the per-launch HIP events of the roofline record (two events around every conv launch: a few % at 256 -> 1024, a third of the
+    # step at the launch-bound 64 -> 256 tiles)
+    r2 = subprocess.run(cmd + ["--no-roofline"], capture_output=True, text=True, timeout=900)
+    l2 = [l for l in r2.stdout.strip().splitlines() if l.startswith("{")]
+    if r2.returncode == 0 and l2:
+        d2 = json.loads(l2[-1])
+        out[-1]["value_without_event_timers"] = round(d2["value"], 1)
+        out[-1]["ms_per_step_without_event_timers"] = round(d2["ms_per_step"], 2)
+    print(flags, "->", out[-1]["value"], d["unit"], out[-1]["ms_per_step"], "ms/step; without the event timers", out[-1].get("value_without_event_timers"), flush=True)
 json.dump(out, open(sys.argv[1], "w"), indent=1)

@@ -256,9 +256,9 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
 
 // second stage of the two-stage reduction: blocks [0, nb_dw) sum the weight partials, blocks [nb_dw, gridDim.x) the bias partials
 // (per-slot column sums written by the (chunk 0, ky 0) waves) -- one launch for both
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
-                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
-                                                            const float* __restrict__ db_partials, float* __restrict__ db, int ld) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+                                                  int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
+                                                  const float* __restrict__ db_partials, float* __restrict__ db, int ld, float (*red)[64]) {
     if ((int)blockIdx.x >= nb_dw) {
         const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
         if (co >= cout) return;
@@ -279,7 +279,6 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     // k = w, w + 4, ... with four accumulators each, i.e. 16 independent load chains per output, and are combined through LDS in a fixed
     // order (bitwise reproducible).  One thread per output walked its 96-768 slots alone: ~1.5 blocks per CU, latency bound (34 us for the
     // 37 MB of SPAN's 104 -> 104 partials, 15 % of its step).
-    __shared__ float red[4][64];
     const int64_t total = (int64_t)cout * taps * cin;
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)nb_dw * 64) {
@@ -314,6 +313,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
+                                                            const float* __restrict__ db_partials, float* __restrict__ db, int ld) {
+    __shared__ float red[4][64];
+    wgrad_reduce_body(partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps, nb_dw, db_partials, db, ld, red);
+}
+// The reductions of the convs of ONE fused dense-block launch (tr_wgrad3x3_multi) in one launch: blockIdx.y picks the conv.  Five launches of 6 us for
+// 18-110 k outputs each were 7 % of the configs[2] step (64 -> 256 tiles) and 0.8 % of the headline step.
+struct ReduceOne {
+    const float* partials; float* dw; const float* db_partials; float* db;
+    int cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps, nb_dw, nb_db, ld;
+};
+struct ReduceMulti { ReduceOne r[8]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceMulti m) {
+    __shared__ float red[4][64];
+    const ReduceOne& q = m.r[blockIdx.y];
+    if ((int)blockIdx.x >= q.nb_dw + q.nb_db) return;           // the grid is as wide as the widest conv
+    wgrad_reduce_body(q.partials, q.dw, q.cin, q.cout, q.nslots, q.nchunks, q.ncg, q.cgw, q.accumulate, q.taps, q.nb_dw, q.db_partials, q.db, q.ld, red);
+}
 
 // The same reduction on 16-byte partial reads (cin % 4 == 0): a lane owns four consecutive input channels of one (co, tap) row -- contiguous in the
 // partial blocks ([..][tap][ci 32]) -- so a block covers 256 outputs and every load chain carries four times the bytes (SwinIR-M's 156 reductions per step cost 9.5 us each
@@ -750,6 +769,24 @@ extern "C" int tr_wgrad3x3_multi(void* stream, const tr_wgrad3x3_desc* descs, in
             if (rc) return rc;
         }
         return 0;
+    }
+    if (ndesc <= 8) {
+        ReduceMulti m;
+        unsigned gx = 1;
+        for (int k = 0; k < ndesc; ++k) {
+            const tr_wgrad3x3_desc& d = descs[k];
+            const int nchunks = (d.cin + 31) / 32, ncg = (d.cout + 31) / 32;
+            const size_t dw_floats = (size_t)nslots * nchunks * ncg * 32 * 9 * 32;
+            int64_t b = ((int64_t)d.cout * 9 * d.cin + 63) / 64;
+            if (b > 8192) b = 8192;
+            ReduceOne& q = m.r[k];
+            q.partials = d.partials; q.dw = d.dw; q.db_partials = d.partials + dw_floats; q.db = d.db;
+            q.cin = d.cin; q.cout = d.cout; q.nslots = nslots; q.nchunks = nchunks; q.ncg = ncg; q.cgw = 32; q.accumulate = d.accumulate; q.taps = 9;
+            q.nb_dw = (int)b; q.nb_db = d.db ? (d.cout + 255) / 256 : 0; q.ld = d.dw_ld > 0 ? d.dw_ld : d.cin;
+            if ((unsigned)(q.nb_dw + q.nb_db) > gx) gx = (unsigned)(q.nb_dw + q.nb_db);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(gx, (unsigned)ndesc), dim3(256), 0, (hipStream_t)stream, m);
+        return tr::launch_status("tr_wgrad3x3_multi(reduce)");
     }
     for (int k = 0; k < ndesc; ++k) {
         const tr_wgrad3x3_desc& d = descs[k];
