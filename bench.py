@@ -105,6 +105,7 @@ class ConvTimer:
     def __init__(self):
         self.records = []   # (key, flops, ev0, ev1)
         self.enabled = False
+        self.only = None    # timed region: the one kernel group whose launches carry events (the dominant group found in the last warm-up step)
 
     def install(self):
         from trainner_redux_amd import _lib as L, ops
@@ -115,12 +116,14 @@ class ConvTimer:
         def timed(**kw):
             if not timer.enabled:
                 return orig(**kw)
+            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32w4" if kw["compute"] == L.F32_WINOGRAD43 else "f32"
+            ks = kw.get("ksize", 3)
+            if timer.only is not None and (cd, 64 if kw["cout"] > 32 else 32, ks) != timer.only:
+                return orig(**kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             orig(**kw)
             e1.record()
-            cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32w4" if kw["compute"] == L.F32_WINOGRAD43 else "f32"
-            ks = kw.get("ksize", 3)
             npix = float(kw["n"]) * kw["h"] * kw["w"]
             flops = 2.0 * npix * ks * ks * kw["cin"] * kw["cout"]
             # algorithmic bytes of the launch: input read once (a quarter of the pixels under nearest-2x), every output / side view once
@@ -136,9 +139,9 @@ class ConvTimer:
         ops.conv3x3 = timed
         # archs call `ops.conv3x3(...)` through the module attribute, so the wrapper is seen everywhere
 
-    def summary(self):
+    def summary(self, records=None):
         agg = {}
-        for key, flops, e0, e1, nbytes, fam in self.records:
+        for key, flops, e0, e1, nbytes, fam in (self.records if records is None else records):
             ms = e0.elapsed_time(e1)
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, {}])
             a[0] += 1
@@ -320,8 +323,9 @@ def workload_key(args, n, s):
     return f"{args.arch}/{args.losses}/{args.compute}/batch{n}/lq{s}" + (f"/blocks{args.blocks}" if args.arch == "esrgan" else "") + ("/gan" if args.gan else "")
 
 
-def roofline(args, agg, dt, n, s):
-    """The dominant kernel group (by summed launch time inside the timed region) against the roofline that bounds it.
+def roofline(args, agg, dt, n, s, warm=None):
+    """The dominant kernel group (by summed launch time) against the roofline that bounds it.  `agg`: launches timed inside the timed region (only the
+    dominant group when the last warm-up step has named it); `warm`: every group, timed in the last warm-up step -- the `all` table's other rows.
 
     executed FLOPs = algorithmic 3x3-convolution FLOPs / WINO_FACTOR (1 for the direct kernels); arithmetic intensity = executed FLOPs /
     algorithmic bytes; bound = mfma when that intensity lies above the ridge (peak FLOP/s / 8 TB/s), else hbm.  `achieved` / `frac` are the
@@ -355,7 +359,16 @@ def roofline(args, agg, dt, n, s):
             e["traffic_over_algorithmic"] = tr / (nbytes / cnt)
         return tkey, e
 
-    table = dict(entry(k, v) for k, v in agg.items())
+    table = {}
+    for k, v in (warm or {}).items():
+        if k not in agg:
+            tk, e0 = entry(k, v)
+            e0["measured_in"] = "last warm-up step (1 step)"
+            table[tk] = e0
+    for k, v in agg.items():
+        tk, e0 = entry(k, v)
+        e0["measured_in"] = "timed region"
+        table[tk] = e0
     key = max(agg, key=lambda k: agg[k][2])
     tkey, e = entry(key, agg[key])
     names = {"f32w": "winograd_f32_kernel (fused Winograd F(2x2,3x3), fp32 MFMA)", "f32w4": "winograd43_f32_kernel (fused Winograd F(4x4,3x3), fp32 MFMA)"}
@@ -481,12 +494,27 @@ def main():
         torch.cuda.synchronize()
 
     log(f"model built; warm-up {args.warmup} steps")
+    # Two events around EVERY conv launch cost a few % of the 256 -> 1024 step and a third of the launch-bound 64 -> 256 steps (the timestamps serialise
+    # back-to-back launches).  So: every group is timed in the LAST WARM-UP step (untimed region) -- that fills `roofline.all` and tells which group
+    # dominates -- and inside the timed region only the dominant group's launches carry events (45 per step on the headline workload).
     it = 0
-    for _ in range(args.warmup):
+    warm_records = None
+    for k in range(args.warmup):
         it += 1
-        step(it)
+        if k == args.warmup - 1 and not args.no_roofline:
+            fence()
+            timer.enabled = True
+            step(it)
+            fence()
+            timer.enabled = False
+            warm_records, timer.records = timer.records, []
+        else:
+            step(it)
     fence()
-    log(f"warm-up done; timing {args.steps} steps")
+    if warm_records:
+        wagg = timer.summary(warm_records)
+        timer.only = max(wagg, key=lambda k: wagg[k][2])
+    log(f"warm-up done; timing {args.steps} steps" + (f" (events on the {timer.only} launches only)" if timer.only else ""))
     timer.enabled = not args.no_roofline
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -515,7 +543,7 @@ def main():
                        "l_g_total": stats.get("l_g_total")},
         }
         if not args.no_roofline and timer.records:
-            out["roofline"] = roofline(args, timer.summary(), dt, n, s)
+            out["roofline"] = roofline(args, timer.summary(), dt, n, s, timer.summary(warm_records) if warm_records else None)
         if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
             # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the
             # split-bf16 path of the fp32-forced VGG head (3 bf16 MFMAs per product; measured 3e-6 rel-L2 per conv vs exact fp32)
