@@ -189,3 +189,45 @@ def test_vgg_style_discriminator_trains_in_the_gan_step(cuda):
     assert {"l_g_l1", "l_g_gan", "l_d_real", "l_d_fake", "grad_norm_g", "grad_norm_d"} <= set(log) and all(v == v and abs(v) < 1e6 for v in log.values()), log
     assert (model.net_g.flat_parameters()[0] - wg0).abs().max() > 0 and (model.net_d.flat_parameters()[0] - wd0).abs().max() > 0
     assert int(model.net_d.state_dict()["bn0_1.num_batches_tracked"]) == 6          # three training-mode D forwards per step (sr_model.py:547,757-758)
+
+
+@pytest.mark.parametrize("compute", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("kind", ["unetdiscriminatorsn"])
+def test_discriminator_batch_is_the_union_of_its_halves(cuda, compute, kind):
+    """configs[2]'s discriminator at the bench size (batch 8, 256 x 256) through the sample-independence property: logits and the input gradient of a batch
+    equal its halves' bit for bit, parameter gradients are their sum.  Eval-mode spectral norm (stored u / v: training mode advances the power iteration
+    per call).  (The VGG-style discriminator couples the samples through BatchNorm's batch statistics in training mode and has no eval-mode backward.)"""
+    from trainner_redux_amd.archs import build_network
+
+    torch.manual_seed(3)
+    if kind == "unetdiscriminatorsn":
+        net, size = build_network(dict(type=kind, num_in_ch=3, num_feat=64, skip_connection=True)), 256
+    else:
+        net, size = build_network(dict(type=kind, num_in_ch=3, num_feat=32, input_size=128)), 128
+    net = net.to(cuda).eval()
+    net.compute_dtype = compute
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(8, 3, size, size, generator=g).to(cuda)
+    for _ in range(5):                       # a few power iterations first: the random initial u / v under-estimate sigma by orders of magnitude (fp16 overflows)
+        net.forward_hip(x[:1], train=True)
+    net._saved = None
+    _, garr = net.flat_parameters()
+
+    def run(parts):
+        garr.zero_()
+        outs, gins = [], []
+        for sl in parts:
+            y = net.forward_hip(x[sl], train=False)
+            gy = torch.ones_like(y) / y[0].numel()
+            gin = torch.zeros_like(x[sl])
+            net.backward_hip(gy, param_grads=True, input_grad=gin, input_grad_accumulate=False)
+            outs.append(y.clone()); gins.append(gin)
+        torch.cuda.synchronize()
+        return torch.cat(outs), torch.cat(gins), garr.double().clone()
+
+    y_f, gi_f, g_f = run([slice(0, 8)])
+    y_h, gi_h, g_h = run([slice(0, 4), slice(4, 8)])
+    assert torch.equal(y_f, y_h) and torch.equal(gi_f, gi_h), ((y_f - y_h).abs().max().item(), (gi_f - gi_h).abs().max().item())
+    rel = ((g_f - g_h).norm() / g_h.norm()).item()
+    print(f"{kind} {compute}: logits and input gradient identical, parameter gradient rel-L2 {rel:.2e}")
+    assert rel < 1e-5, rel
