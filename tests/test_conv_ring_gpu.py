@@ -161,58 +161,6 @@ def test_ring_forward_generic_epilogue(cuda, compute_name, case):
 
 @pytest.mark.parametrize("compute_name", ["bf16", "f16"])
 @pytest.mark.parametrize("case", [
-    # (geom, cin, cout, act, fp32 residual?, per-sample scale?, out fp32?)
-    ((2, 40, 72), 96, 64, "mish", True, True, True),         # MoSR's fc2: Mish, DropPath scale, residual into the fp32 stream, pre-activation kept
-    ((1, 17, 33), 96, 64, "mish", True, False, True),
-    ((3, 24, 40), 96, 64, "mish", False, False, False),      # the last block: compute-dtype output, no residual
-    ((2, 40, 72), 64, 96, "silu", False, True, False),       # half a last group through the generic body
-    ((1, 33, 64), 128, 32, "gelu", True, True, True),
-    ((2, 20, 36), 64, 64, "none", True, True, True),         # per-sample scale without an activation
-])
-def test_ring_smooth_activations_with_saved_pre_activation(cuda, compute_name, case):
-    """GELU / SiLU / Mish in the ring kernel's generic body: v = act(conv + bias) * scale[sample] (* scale1 + res1), out2 = the PRE-activation (what the
-    backward's `tr_act_grad` / derivative masks read) -- the gated block's fc2 (mosr_arch.py; spandrel MoSR GatedCNNBlock) served by the ring kernel."""
-    from trainner_redux_amd import _lib as L, ops
-
-    (n, h, w), cin, cout, act, with_res, with_scale, out32 = case
-    compute, dt = _ct(L, compute_name)
-    g = torch.Generator().manual_seed(17 + cin + cout + h)
-    x = _rnd(torch.randn(n, cin, h, w, generator=g), dt)
-    wt = _rnd(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9), dt)
-    b = torch.randn(cout, generator=g)
-    r1 = torch.randn(n, cout, h, w, generator=g)
-    ss = torch.rand(n, generator=g) + 0.5
-    pre = F.conv2d(x, wt, b, padding=1)
-    v = {"mish": F.mish, "silu": F.silu, "gelu": F.gelu, "none": (lambda t: t)}[act](pre)
-    if with_scale:
-        v = v * ss.view(n, 1, 1, 1)
-    if with_res:
-        v = v + r1
-    xd, bias, r1d, ssd = nhwc(x).to(cuda, dt), b.to(cuda), nhwc(r1).to(cuda), ss.to(cuda)
-    wp = _pack(ops, wt.to(cuda), cin, cout, compute, cuda)
-    out = torch.full((n, h, w, cout + 8), 3.0, dtype=torch.float32 if out32 else dt, device=cuda)
-    out2 = torch.full((n, h, w, cout + 8), 5.0, dtype=dt, device=cuda)
-    kw = dict(out2=ops.view(out2, 0, cout))
-    if with_res:
-        kw.update(res1=ops.view(r1d), scale1=1.0)
-    if with_scale:
-        kw.update(sample_scale=ssd)
-    with ops.tuned(conv_impl=2):
-        ops.conv3x3(n=n, h=h, w=w, cin=cin, cout=cout, compute=compute, inp=ops.view(xd), out=ops.view(out, 0, cout), wpacked=wp, bias=bias,
-                    act={"mish": L.ACT_MISH, "silu": L.ACT_SILU, "gelu": L.ACT_GELU, "none": L.ACT_NONE}[act], **kw)
-    inst = _ring(ops)
-    assert inst % 10 == (5 if with_res else 3), inst          # the generic body
-    got, g2 = out.float().cpu(), out2.float().cpu()
-    if out32:
-        assert rel_l2(nchw(got[..., :cout]), v) < 3e-6, rel_l2(nchw(got[..., :cout]), v)
-    else:
-        _check16(nchw(got[..., :cout]), v, dt, case)
-    _check16(nchw(g2[..., :cout]), pre if act != "none" else v, dt, case)
-    assert torch.all(got[..., cout:] == 3.0) and torch.all(g2[..., cout:] == 5.0)
-
-
-@pytest.mark.parametrize("compute_name", ["bf16", "f16"])
-@pytest.mark.parametrize("case", [
     # (geom, g channels (launch cin), x channels (launch cout), ring_cfg, out fp32?, mask fp32?, second output?, generic forced?)
     ((2, 40, 72), 64, 32, -1, False, False, False, False),       # x4's gradient: fast form 1, resident weights + LDS-staged mask tile
     ((1, 17, 33), 96, 32, -1, False, False, False, False),

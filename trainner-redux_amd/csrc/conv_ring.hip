@@ -279,28 +279,6 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const float4 (&rd)
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        // generic body only: the smooth activations of the gated / transformer archs (MoSR's fc2: Mish + residual, pre-activation to out2 for the
-        // backward) and the per-sample DropPath scale, with conv_epilogue_impl's order: act, scale, residuals, mask (conv3x3.hip)
-        float pre[8];
-        if constexpr (!FAST) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pre[i] = v[i];
-            if (a.act == TR_ACT_GELU) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752f));
-            } else if (a.act == TR_ACT_SILU) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = v[i] / (1.f + __expf(-v[i]));
-            } else if (a.act == TR_ACT_MISH) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = tr::mish(v[i]);
-            }
-            if (a.sample_scale) {
-                const float ss = a.sample_scale[rowpix / ((int64_t)a.h * a.w)];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] *= ss;
-            }
-        }
         if constexpr (SIDE == 2) {
             const uint4 qa = raw.q[hf * 4], qb = raw.q[hf * 4 + 1];
             const float rr[8] = {__uint_as_float(qa.x), __uint_as_float(qa.y), __uint_as_float(qa.z), __uint_as_float(qa.w),
@@ -343,10 +321,7 @@ __device__ __forceinline__ void epi_finish(const ConvArgs& a, const float4 (&rd)
             }
         } else if (ok) {
             store8(a.out, pix, co, v, 1.f);
-            if (a.out2.ptr) {
-                if (a.act >= TR_ACT_GELU) store8(a.out2, pix, co, pre, 1.f);       // GELU / SiLU / Mish: out2 keeps the pre-activation
-                else store8(a.out2, pix, co, v, a.out2_scale);
-            }
+            if (a.out2.ptr) store8(a.out2, pix, co, v, a.out2_scale);
         }
     }
 }
@@ -909,9 +884,8 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     if (d->ksize != 3 || (d->compute != TR_BF16 && d->compute != TR_F16)) return -1;
     if (d->in_mode == TR_IN_VALID || d->in_mode == TR_IN_FULL) return -1;
     if (d->cin % 32 != 0 || d->cout % 8 != 0) return -1;
-    const bool smooth = d->act == TR_ACT_GELU || d->act == TR_ACT_SILU || d->act == TR_ACT_MISH;      // generic body only
-    if (d->act != TR_ACT_NONE && d->act != TR_ACT_LRELU && d->act != TR_ACT_RELU && !smooth) return -1;
-    if (d->mask_mode != 0 || d->cout > 1024) return -1;
+    if (d->act != TR_ACT_NONE && d->act != TR_ACT_LRELU && d->act != TR_ACT_RELU) return -1;
+    if (d->mask_mode != 0 || d->sample_scale || d->cout > 1024) return -1;
     int side = 0;                                                    // the two side-input shapes of the hot path (ring_epilogue_row)
     if (d->mask.ptr && !d->res1.ptr && !d->res2.ptr) side = 1;
     else if (d->res1.ptr && d->res1.dtype == TR_F32 && !d->mask.ptr && (!d->res2.ptr || d->res2.dtype == TR_F32)) side = 2;
@@ -925,7 +899,7 @@ int conv3x3_ring(hipStream_t st, ConvArgs& a, const tr_conv3x3_desc* d) {
     else fast = d->act == TR_ACT_NONE && d->out.dtype == TR_F32 && (!d->out2.ptr || d->out2.dtype == ct);
     auto img_ok = [&](const tr_view& v) { return !v.ptr || (int64_t)d->h * d->w * v.cstride * tr::esize(v.dtype) < (int64_t)0x7fff0000; };
     if (d->cout % 32 != 0 || !img_ok(d->out) || !img_ok(d->out2) || !img_ok(d->res1) || !img_ok(d->res2) || !img_ok(d->mask)) fast = false;   // buffer addressing of the fast forms
-    if (tn.ring_generic || smooth || d->sample_scale) fast = false;  // ring_generic: A/B switch (and the parity tests of the generic body)
+    if (tn.ring_generic) fast = false;                               // A/B switch (and the parity tests of the generic body)
     const int epi = fast ? side : side + 3;
     if (!vec16_ok(d->out) || !vec16_ok(d->out2) || !vec16_ok(d->res1) || !vec16_ok(d->res2) || !vec16_ok(d->mask)) return -1;
     if ((int64_t)a.hin * a.win * d->in.cstride * 2 >= (int64_t)0x7fff0000) return -1;            // buffer addressing: one image below 2 GiB
