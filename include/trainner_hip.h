@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define TR_ABI_VERSION 3   /* 3: tr_batchnorm_fwd / _bwd; 2: tr_tune_set / tr_tune_get; tr_adamw_ema skips the update on the device when *grad_norm is not finite */
+#define TR_ABI_VERSION 4   /* 4: tr_layernorm_bwd takes dx2 / sample_scale / pix_per_sample; 3: tr_batchnorm_fwd / _bwd; 2: tr_tune_set / tr_tune_get; tr_adamw_ema skips the update on the device when *grad_norm is not finite */
 
 enum { TR_F32 = 0, TR_BF16 = 1, TR_F16 = 2, TR_BF16X3 = 3 };   /* TR_F16: the reference's default AMP dtype (use_amp without amp_bf16) */
 enum { TR_EINVAL = -1, TR_EUNSUPPORTED = -2, TR_EALIGN = -3 };
@@ -312,10 +312,14 @@ int tr_gan_loss(void* stream, const tr_gan_loss_desc* d);
  * the following GEMM); mean / rstd (ntok floats each, optional) are kept for the backward. */
 int tr_layernorm(void* stream, tr_view x, tr_view y, int64_t ntok, int c, const float* gamma, const float* beta, float eps,
                  float* mean_out, float* rstd_out);
-/* dx = (res ? res : 0) + dLN/dx ; dgamma / dbeta (+)= ...  (fixed-order reduction; workspace from the _bytes call) */
+/* dx = (res ? res : 0) + dLN/dx ; dgamma / dbeta (+)= ...  (fixed-order reduction; workspace from the _bytes call).
+ * dx2 (optional view, any dtype): dx2 = dx * (sample_scale ? sample_scale[token / pix_per_sample] : 1) -- the compute-dtype copy of the residual-stream
+ * gradient, scaled by the next branch's DropPath keep mask, that the following weight-gradient / input-gradient GEMMs read (drct_arch.py:572-573 backward);
+ * it saves the separate scale-and-convert pass over the stream. */
 size_t tr_layernorm_bwd_workspace_bytes(int c);
 int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok, int c, const float* gamma, const float* mean, const float* rstd,
-                     tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes);
+                     tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes,
+                     tr_view dx2, const float* sample_scale, int64_t pix_per_sample);
 
 /* (Shifted-)window multi-head self-attention core (:175-223, roll / partition / reverse :78-109,:532-568, mask :492-521):
  * per 8x8 window and head  softmax(q*scale @ k^T + table[rel_index] + shift_mask) @ v, windows taken from the image rolled by

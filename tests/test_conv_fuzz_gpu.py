@@ -341,9 +341,22 @@ def test_layernorm_random_shape_matches_torch(cuda, seed):
     dx = torch.full((ntok, cp), 9.0, device=cuda)
     dgam, dbet = torch.full((c,), 2.0, device=cuda), torch.full((c,), 2.0, device=cuda)
     ws = torch.empty(ops.layernorm_bwd_workspace_bytes(c) // 4, device=cuda)
+    # second output: the compute-dtype copy of dx scaled per sample (the DropPath keep mask of the branch that reads it), drct_arch.py:572-573 backward
+    mode2 = r.choice(["none", "copy", "scaled"])
+    pps = r.choice([1, 7, 64, 1000])
+    d2dt = r.choice([torch.bfloat16, torch.float16, torch.float32])
+    dx2 = torch.full((ntok, cp), 11.0, dtype=d2dt, device=cuda)
+    ssc = (torch.rand((ntok + pps - 1) // pps, generator=g) + 0.5)
+    kw2 = {} if mode2 == "none" else (dict(dx2=ops.view(dx2, 0, c)) if mode2 == "copy" else dict(dx2=ops.view(dx2, 0, c), sample_scale=ssc.to(cuda), pix_per_sample=pps))
+    keep_alive = kw2.get("sample_scale")      # noqa: F841
     ops.layernorm_bwd(ops.view(gyd, 0, c), ops.view(xd, 0, c), ntok, c, gd, mean, rstd, ops.view(resd, 0, c) if with_res else ops.NULL_VIEW, ops.view(dx, 0, c), dgam, dbet,
-                      ws)
+                      ws, **kw2)
     ref_dx = xr.grad + (res if with_res else 0)
+    if mode2 != "none":
+        ref2 = ref_dx * (ssc.repeat_interleave(pps)[:ntok].view(ntok, 1) if mode2 == "scaled" else 1.0)
+        tol2 = 5e-6 if d2dt == torch.float32 else (4e-3 if d2dt == torch.bfloat16 else 6e-4)
+        assert rel_l2(dx2[:, :c].float().cpu(), ref2) < tol2, (what, mode2, pps, d2dt, rel_l2(dx2[:, :c].float().cpu(), ref2))
+        assert torch.all(dx2[:, c:] == 11.0), (what, "bytes behind dx2 were written")
     assert rel_l2(dx[:, :c].cpu(), ref_dx) < 5e-6, (what, rel_l2(dx[:, :c].cpu(), ref_dx))
     assert torch.all(dx[:, c:] == 9.0), (what, "bytes behind dx were written")
     assert rel_l2(dgam.cpu() - 2.0, gr.grad) < 2e-5 and rel_l2(dbet.cpu() - 2.0, br.grad) < 2e-5, (what, rel_l2(dgam.cpu() - 2.0, gr.grad), rel_l2(dbet.cpu() - 2.0, br.grad))

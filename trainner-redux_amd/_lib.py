@@ -10,7 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtrainner_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, BF16, F16, BF16X3 = 0, 1, 2, 3
 F32_WINOGRAD43 = 101    # ... tr_conv3x3_winograd43_f32 (F(4x4, 3x3), weights from tr_pack_winograd43)
@@ -131,7 +131,7 @@ SYMBOLS = {
     "tr_layernorm": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "tr_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int]),
     "tr_layernorm_bwd": (C.c_int, [C.c_void_p, View, View, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, View, View, C.c_void_p, C.c_void_p,
-                                   C.c_int, C.c_void_p, C.c_size_t]),
+                                   C.c_int, C.c_void_p, C.c_size_t, View, C.c_void_p, C.c_int64]),
     "tr_window_attention": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),
     "tr_window_attention_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "tr_window_attention_bwd": (C.c_int, [C.c_void_p, C.POINTER(WindowAttnDesc)]),

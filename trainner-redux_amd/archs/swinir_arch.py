@@ -431,11 +431,15 @@ class SwinIR(FlatParamModule):
         free = [Z(B, h, w, CP, dt=f32) for _ in range(5)]      # fp32 gradient-stream buffers, recycled block after block (stream order)
         gx = free.pop()
         fm, fr = sv["fnorm"]
-        ops.layernorm_bwd(V(g_lnf, 0, C), V(sv["x_final"], 0, C), T, C, self.norm.weight.data, fm, fr, ops.NULL_VIEW, V(gx, 0, C), self.norm.weight.grad,
-                          self.norm.bias.grad, wg)
         keepm = sv["keep"]
         blocks = list(self._blocks())
         gcd, g_pre, dqkv = Z(B, h, w, CP), Z(B, h, w, HP), Z(B, h, w, C3P)
+        # Every LayerNorm backward also writes the compute-dtype copy of its output that the NEXT GEMMs read (`dx2`, scaled by that branch's DropPath
+        # keep mask): the separate scale-and-convert pass over the gradient stream (73 launches per step) is gone.  `copied` says that `gcd` already
+        # holds the copy the next consumer needs.
+        ops.layernorm_bwd(V(g_lnf, 0, C), V(sv["x_final"], 0, C), T, C, self.norm.weight.data, fm, fr, ops.NULL_VIEW, V(gx, 0, C), self.norm.weight.grad,
+                          self.norm.bias.grad, wg, dx2=V(gcd, 0, C))          # the last block closes an RSTB: its tail conv reads the unscaled copy
+        copied = True
         g_ln, g_ao = Z(B, h, w, CP, dt=f32), Z(B, h, w, CP)
         g_layer_out = None
         for i, j, nh, blk in reversed(blocks):
@@ -445,22 +449,24 @@ class SwinIR(FlatParamModule):
                 # RSTB tail: X_next = conv(x_out) + layer_in
                 layer = getattr(self.layers, str(i))
                 g_layer_out = gx
-                ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T)
+                if not copied:
+                    ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T)
                 wgrad_conv(layer.conv, V(sv[("lconv_in", i)]), V(gcd), h, w)
                 gx = free.pop()
                 ops.conv3x3(cin=CP, cout=C, inp=V(gcd), out=V(gx), wpacked=st[("lconv", i)][1], **ig)
+                copied = False
             # ---- MLP branch: x_out = x_mid + keep * fc2(gelu(fc1(LN2(x_mid))))
-            ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T, sample_scale=keep, pix_per_sample=h * w)
+            if not copied:
+                ops.axpby(V(gx), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T, sample_scale=keep, pix_per_sample=h * w)
             wgrad_lin(blk.mlp.fc2, V(s["post"]), V(gcd))
             ops.conv3x3(cin=CP, cout=self.hid, inp=V(gcd), out=V(g_pre), wpacked=st[("fc2", i, j)][1], mask=V(s["pre"]), mask_mode=1, **tg)
             wgrad_lin(blk.mlp.fc1, V(s["ln2"]), V(g_pre))
             ops.conv3x3(cin=HP, cout=C, inp=V(g_pre), out=V(g_ln), wpacked=st[("fc1", i, j)][1], **tg)
             g_mid = free.pop()
             ops.layernorm_bwd(V(g_ln, 0, C), V(s["x_mid"], 0, C), T, C, blk.norm2.weight.data, s["m2"], s["r2"], V(gx, 0, C), V(g_mid, 0, C),
-                              blk.norm2.weight.grad, blk.norm2.bias.grad, wg)
+                              blk.norm2.weight.grad, blk.norm2.bias.grad, wg, dx2=V(gcd, 0, C), sample_scale=keep, pix_per_sample=h * w)
             free.append(gx)
-            # ---- attention branch: x_mid = x_in + keep * proj(attn(qkv(LN1(x_in))))
-            ops.axpby(V(g_mid), 1.0, ops.NULL_VIEW, 0.0, V(gcd), T, sample_scale=keep, pix_per_sample=h * w)
+            # ---- attention branch: x_mid = x_in + keep * proj(attn(qkv(LN1(x_in)))) ; gcd = keep * g_mid came out of the LayerNorm backward above
             wgrad_lin(blk.attn.proj, V(s["ao"]), V(gcd))
             ops.conv3x3(cin=CP, cout=C, inp=V(gcd), out=V(g_ao), wpacked=st[("proj", i, j)][1], **tg)
             ops.window_attention_bwd(V(s["qkv"]), V(g_ao), V(dqkv), blk.attn.relative_position_bias_table.data,
@@ -475,8 +481,11 @@ class SwinIR(FlatParamModule):
                 free.append(g_layer_out)
                 res = tmp
             g_in = free.pop()
+            # what reads g_in next: the MLP branch of block (i, j - 1) -- its keep mask -- or, below an RSTB boundary, the tail conv of layer i - 1 (unscaled)
+            nxt = dict(dx2=V(gcd, 0, C), sample_scale=keepm.get((i, j - 1)), pix_per_sample=h * w) if j > 0 else (dict(dx2=V(gcd, 0, C)) if i > 0 else {})
             ops.layernorm_bwd(V(g_ln, 0, C), V(s["x_in"], 0, C), T, C, blk.norm1.weight.data, s["m1"], s["r1"], V(res, 0, C), V(g_in, 0, C),
-                              blk.norm1.weight.grad, blk.norm1.bias.grad, wg)
+                              blk.norm1.weight.grad, blk.norm1.bias.grad, wg, **nxt)
+            copied = bool(nxt)
             free.append(g_mid)
             if res is not g_mid:
                 free.append(res)

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(tr_view x, tr_vi
 template <int NK>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(tr_view g, tr_view x, int64_t ntok, int c, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, tr_view res,
-                                                             tr_view dx, float* __restrict__ partials) {
+                                                             tr_view dx, float* __restrict__ partials, tr_view dx2, const float* __restrict__ sscale,
+                                                             int64_t pps) {
     __shared__ float sh[4][2][NK * 64];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(tr_view g, tr_view x
                     float o = rs[u] * (a[u][k] - m1 - xh[u][k] * m2);
                     if (res.ptr) o += tr::view_load(res, t, ch);
                     tr::view_store(dx, t, ch, o);
+                    if (dx2.ptr) tr::view_store(dx2, t, ch, sscale ? o * sscale[t / pps] : o);
                 }
             }
         }
@@ -211,7 +213,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(tr_view g, tr_view x
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(tr_view g, tr_view x, int64_t ntok, int c, const float* __restrict__ gamma,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd, tr_view res,
-                                                                 tr_view dx, float* __restrict__ partials) {
+                                                                 tr_view dx, float* __restrict__ partials, tr_view dx2, const float* __restrict__ sscale,
+                                                                 int64_t pps) {
     __shared__ float sh[4][2][NV * 64];
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, sub = l & 15, row = l >> 4;
     const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(tr_view g, tr_vi
             if (!live[u]) continue;
             const int64_t t = t0 + u * 4 + row;
             const float m1 = s1[u] / (float)c, m2 = s2[u] / (float)c;
+            const float ss = (dx2.ptr && sscale) ? sscale[t / pps] : 1.f;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int ch = (sub + 16 * k) * 4;
@@ -277,6 +281,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(tr_view g, tr_vi
                     o.x = rs[u] * (av.x - m1 - h.x * m2) + r.x; o.y = rs[u] * (av.y - m1 - h.y * m2) + r.y;
                     o.z = rs[u] * (av.z - m1 - h.z * m2) + r.z; o.w = rs[u] * (av.w - m1 - h.w * m2) + r.w;
                     tr::view_store4(dx, t, ch, o, true);
+                    if (dx2.ptr) tr::view_store4(dx2, t, ch, make_float4(o.x * ss, o.y * ss, o.z * ss, o.w * ss), true);
                 }
             }
         }
@@ -555,7 +560,11 @@ extern "C" int tr_layernorm(void* stream, tr_view x, tr_view y, int64_t ntok, in
 }
 
 extern "C" int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok, int c, const float* gamma, const float* mean, const float* rstd,
-                                tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes) {
+                                tr_view res, tr_view dx, float* dgamma, float* dbeta, int accumulate, float* partials, size_t partials_bytes,
+                                tr_view dx2, const float* sample_scale, int64_t pix_per_sample) {
+    TR_REQUIRE(!dx2.ptr || dx2.c >= c, TR_EINVAL, "tr_layernorm_bwd: dx2 view too narrow");
+    TR_REQUIRE(!sample_scale || (dx2.ptr && pix_per_sample > 0), TR_EINVAL, "tr_layernorm_bwd: sample_scale needs dx2 and pix_per_sample");
+    if (!sample_scale) pix_per_sample = 1;
     TR_REQUIRE(g.ptr && x.ptr && dx.ptr && gamma && mean && rstd && dgamma && dbeta && partials && ntok > 0 && c > 0 && c <= LN_MAXK * 64, TR_EINVAL,
                "tr_layernorm_bwd: bad arguments");
     // a wave takes two tokens per iteration; at least 8 iterations per wave so that the partial rows (one per block, summed by the
@@ -565,15 +574,15 @@ extern "C" int tr_layernorm_bwd(void* stream, tr_view g, tr_view x, int64_t ntok
                (size_t)nb * 2 * c * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     const int nk = (c + 63) / 64;
-    if (c % 4 == 0 && nk <= 4 && tr::view_vec4_ok(g) && tr::view_vec4_ok(x) && tr::view_vec4_ok(res) && tr::view_vec4_ok(dx)) {
+    if (c % 4 == 0 && nk <= 4 && tr::view_vec4_ok(g) && tr::view_vec4_ok(x) && tr::view_vec4_ok(res) && tr::view_vec4_ok(dx) && tr::view_vec4_ok(dx2)) {
         nb = (int)grid_for(ntok * 8, LN_BWD_BLOCKS);       // eight tokens per wave iteration
-#define TR_LN_BWDV(NV) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV>, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials)
+#define TR_LN_BWDV(NV) hipLaunchKernelGGL(layernorm_bwd_vec_kernel<NV>, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials, dx2, sample_scale, pix_per_sample)
         if (nk <= 1) TR_LN_BWDV(1); else if (nk <= 2) TR_LN_BWDV(2); else if (nk <= 3) TR_LN_BWDV(3); else TR_LN_BWDV(4);
 #undef TR_LN_BWDV
         hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3((2 * c + 31) / 32), dim3(1024), 0, st, partials, nb, c, dgamma, dbeta, accumulate);
         return tr::launch_status("tr_layernorm_bwd");
     }
-#define TR_LN_BWD(NK) hipLaunchKernelGGL(layernorm_bwd_kernel<NK>, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials)
+#define TR_LN_BWD(NK) hipLaunchKernelGGL(layernorm_bwd_kernel<NK>, dim3(nb), dim3(256), 0, st, g, x, ntok, c, gamma, mean, rstd, res, dx, partials, dx2, sample_scale, pix_per_sample)
     if (nk <= 1) TR_LN_BWD(1); else if (nk <= 2) TR_LN_BWD(2); else if (nk <= 3) TR_LN_BWD(3); else if (nk <= 4) TR_LN_BWD(4);
     else if (nk <= 6) TR_LN_BWD(6); else if (nk <= 8) TR_LN_BWD(8); else TR_LN_BWD(12);
 #undef TR_LN_BWD

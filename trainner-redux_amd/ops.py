@@ -306,9 +306,11 @@ def layernorm(x: L.View, y: L.View, ntok: int, c: int, gamma: torch.Tensor, beta
 
 
 def layernorm_bwd(g: L.View, x: L.View, ntok: int, c: int, gamma, mean, rstd, res: L.View, dx: L.View, dgamma, dbeta, workspace: torch.Tensor,
-                  accumulate=True):
+                  accumulate=True, dx2: L.View = NULL_VIEW, sample_scale: torch.Tensor | None = None, pix_per_sample: int = 0):
+    """dx2: optional second output = dx * sample_scale[token // pix_per_sample] in the view's dtype (the GEMM-operand copy of the gradient stream)."""
     L.check(L.lib().tr_layernorm_bwd(stream_ptr(), g, x, ntok, c, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), res, dx, dgamma.data_ptr(),
-                                     dbeta.data_ptr(), 1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size()),
+                                     dbeta.data_ptr(), 1 if accumulate else 0, workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                     dx2, sample_scale.data_ptr() if sample_scale is not None else None, pix_per_sample),
             "tr_layernorm_bwd")
 
 
