@@ -256,23 +256,35 @@ __global__ __launch_bounds__(NTHREADS, (CT == TR_F32 && NT == 2) ? 1 : 2) void w
 
 // second stage of the two-stage reduction: blocks [0, nb_dw) sum the weight partials, blocks [nb_dw, gridDim.x) the bias partials
 // (per-slot column sums written by the (chunk 0, ky 0) waves) -- one launch for both
+template <int NW>      // waves per block: 4, or 16 for small weights with many slots (SPAN: 5,408 outputs x 384 slots ran on 85 blocks of 4 waves, 96 slots per wave)
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
                                                   int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
                                                   const float* __restrict__ db_partials, float* __restrict__ db, int ld, float (*red)[64]) {
     if ((int)blockIdx.x >= nb_dw) {
-        const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
-        if (co >= cout) return;
-        const int cg = co / cgw, col = co - cg * cgw;
-        const float* p = db_partials + (int64_t)cg * cgw + col;
-        const int64_t stride = (int64_t)ncg * cgw;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= nslots; k += 4) {
-            s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
+        // bias partials: a block owns 64 columns, its NW waves share the slots (one thread per column walked all 96-384 slots alone: 31 us per launch on SPAN)
+        const int bl = threadIdx.x & 63, bw = threadIdx.x >> 6;
+        const int co = ((int)blockIdx.x - nb_dw) * 64 + bl;
+        float s = 0.f;
+        if (co < cout) {
+            const int cg = co / cgw, col = co - cg * cgw;
+            const float* p = db_partials + (int64_t)cg * cgw + col;
+            const int64_t stride = (int64_t)ncg * cgw;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int k = bw;
+            for (; k + 3 * NW < nslots; k += 4 * NW) {
+                s0 += p[(k + 0) * stride]; s1 += p[(k + NW) * stride]; s2 += p[(k + 2 * NW) * stride]; s3 += p[(k + 3 * NW) * stride];
+            }
+            for (; k < nslots; k += NW) s0 += p[k * stride];
+            s = (s0 + s1) + (s2 + s3);
         }
-        for (; k < nslots; ++k) s0 += p[k * stride];
-        const float s = (s0 + s1) + (s2 + s3);
-        db[co] = accumulate ? db[co] + s : s;
+        red[bw][bl] = s;
+        __syncthreads();
+        if (bw == 0 && co < cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) t += (red[q][bl] + red[q + 1][bl]) + (red[q + 2][bl] + red[q + 3][bl]);
+            db[co] = accumulate ? db[co] + t : t;
+        }
         return;
     }
     // A block owns 64 consecutive outputs (co, tap, ci with ci fastest: coalesced 256-byte partial rows); its four waves take the slots
@@ -296,16 +308,18 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
             const int64_t stride = (int64_t)nchunks * ncg * blk;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // fixed association: reproducible
             int k = wv;
-            for (; k + 12 < nslots; k += 16) {
-                s0 += p[(k + 0) * stride]; s1 += p[(k + 4) * stride]; s2 += p[(k + 8) * stride]; s3 += p[(k + 12) * stride];
+            for (; k + 3 * NW < nslots; k += 4 * NW) {
+                s0 += p[(k + 0) * stride]; s1 += p[(k + NW) * stride]; s2 += p[(k + 2 * NW) * stride]; s3 += p[(k + 3 * NW) * stride];
             }
-            for (; k < nslots; k += 4) s0 += p[k * stride];
+            for (; k < nslots; k += NW) s0 += p[k * stride];
             s = (s0 + s1) + (s2 + s3);
         }
         red[wv][l] = s;
         __syncthreads();
         if (wv == 0 && i < total) {
-            const float t = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) t += (red[q][l] + red[q + 1][l]) + (red[q + 2][l] + red[q + 3][l]);
             float* o = dw + ((int64_t)co * ld + ci) * taps + tap;
             *o = accumulate ? *o + t : t;
         }
@@ -314,11 +328,12 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
 }
 
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
-                                                            int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
-                                                            const float* __restrict__ db_partials, float* __restrict__ db, int ld) {
-    __shared__ float red[4][64];
-    wgrad_reduce_body(partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps, nb_dw, db_partials, db, ld, red);
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_reduce_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+                                                               int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
+                                                               const float* __restrict__ db_partials, float* __restrict__ db, int ld) {
+    __shared__ float red[NW][64];
+    wgrad_reduce_body<NW>(partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps, nb_dw, db_partials, db, ld, red);
 }
 // The reductions of the convs of ONE fused dense-block launch (tr_wgrad3x3_multi) in one launch: blockIdx.y picks the conv.  Five launches of 6 us for
 // 18-110 k outputs each were 7 % of the configs[2] step (64 -> 256 tiles) and 0.8 % of the headline step.
@@ -331,33 +346,45 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(ReduceMulti m) 
     __shared__ float red[4][64];
     const ReduceOne& q = m.r[blockIdx.y];
     if ((int)blockIdx.x >= q.nb_dw + q.nb_db) return;           // the grid is as wide as the widest conv
-    wgrad_reduce_body(q.partials, q.dw, q.cin, q.cout, q.nslots, q.nchunks, q.ncg, q.cgw, q.accumulate, q.taps, q.nb_dw, q.db_partials, q.db, q.ld, red);
+    wgrad_reduce_body<4>(q.partials, q.dw, q.cin, q.cout, q.nslots, q.nchunks, q.ncg, q.cgw, q.accumulate, q.taps, q.nb_dw, q.db_partials, q.db, q.ld, red);
 }
 
 // The same reduction on 16-byte partial reads (cin % 4 == 0): a lane owns four consecutive input channels of one (co, tap) row -- contiguous in the
 // partial blocks ([..][tap][ci 32]) -- so a block covers 256 outputs and every load chain carries four times the bytes (SwinIR-M's 156 reductions per step cost 9.5 us each
 // in the 4-byte form).  Same slot order per output: bitwise
 // equal to the scalar form.  `vst`: dw rows are 16-byte addressable (taps == 1, ld % 4 == 0, aligned base) -> one float4 store.
-__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_reduce_vec_kernel(const float* __restrict__ partials, float* __restrict__ dw, int cin, int cout,
                                                                 int nslots, int nchunks, int ncg, int cgw, int accumulate, int taps, int nb_dw,
                                                                 const float* __restrict__ db_partials, float* __restrict__ db, int ld, int vst) {
+    __shared__ float4 red[NW][64];
     if ((int)blockIdx.x >= nb_dw) {
-        const int co = ((int)blockIdx.x - nb_dw) * blockDim.x + threadIdx.x;
-        if (co >= cout) return;
-        const int cg = co / cgw, col = co - cg * cgw;
-        const float* p = db_partials + (int64_t)cg * cgw + col;
-        const int64_t stride = (int64_t)ncg * cgw;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 4 <= nslots; k += 4) {
-            s0 += p[(k + 0) * stride]; s1 += p[(k + 1) * stride]; s2 += p[(k + 2) * stride]; s3 += p[(k + 3) * stride];
+        // bias partials: a block owns 64 columns, its NW waves share the slots (one thread per column walked all 96-384 slots alone: 31 us per launch on SPAN)
+        const int bl = threadIdx.x & 63, bw = threadIdx.x >> 6;
+        const int co = ((int)blockIdx.x - nb_dw) * 64 + bl;
+        float s = 0.f;
+        if (co < cout) {
+            const int cg = co / cgw, col = co - cg * cgw;
+            const float* p = db_partials + (int64_t)cg * cgw + col;
+            const int64_t stride = (int64_t)ncg * cgw;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int k = bw;
+            for (; k + 3 * NW < nslots; k += 4 * NW) {
+                s0 += p[(k + 0) * stride]; s1 += p[(k + NW) * stride]; s2 += p[(k + 2 * NW) * stride]; s3 += p[(k + 3 * NW) * stride];
+            }
+            for (; k < nslots; k += NW) s0 += p[k * stride];
+            s = (s0 + s1) + (s2 + s3);
         }
-        for (; k < nslots; ++k) s0 += p[k * stride];
-        const float s = (s0 + s1) + (s2 + s3);
-        db[co] = accumulate ? db[co] + s : s;
+        red[bw][bl].x = s;
+        __syncthreads();
+        if (bw == 0 && co < cout) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) t += (red[q][bl].x + red[q + 1][bl].x) + (red[q + 2][bl].x + red[q + 3][bl].x);
+            db[co] = accumulate ? db[co] + t : t;
+        }
         return;
     }
-    __shared__ float4 red[4][64];
     const int64_t total4 = (int64_t)cout * taps * cin / 4;
     const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int64_t base = (int64_t)blockIdx.x * 64; base < total4; base += (int64_t)nb_dw * 64) {
@@ -377,18 +404,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
             float4 s0 = s, s1 = s, s2 = s, s3 = s;   // fixed association per component: the scalar kernel's
 #define TR_ADD4(acc, q) { const float4 v = *(const float4*)(q); acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
             int k = wv;
-            for (; k + 12 < nslots; k += 16) {
-                TR_ADD4(s0, p + (k + 0) * stride) TR_ADD4(s1, p + (k + 4) * stride) TR_ADD4(s2, p + (k + 8) * stride) TR_ADD4(s3, p + (k + 12) * stride)
+            for (; k + 3 * NW < nslots; k += 4 * NW) {
+                TR_ADD4(s0, p + (k + 0) * stride) TR_ADD4(s1, p + (k + NW) * stride) TR_ADD4(s2, p + (k + 2 * NW) * stride) TR_ADD4(s3, p + (k + 3 * NW) * stride)
             }
-            for (; k < nslots; k += 4) TR_ADD4(s0, p + k * stride)
+            for (; k < nslots; k += NW) TR_ADD4(s0, p + k * stride)
 #undef TR_ADD4
             s = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
         }
         red[wv][l] = s;
         __syncthreads();
         if (wv == 0 && on) {
-            const float4 a = red[0][l], b = red[1][l], c = red[2][l], d = red[3][l];
-            float t[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w)};
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < NW; q += 4) {
+                const float4 a = red[q][l], b = red[q + 1][l], c = red[q + 2][l], d = red[q + 3][l];
+                t[0] += (a.x + b.x) + (c.x + d.x); t[1] += (a.y + b.y) + (c.y + d.y); t[2] += (a.z + b.z) + (c.z + d.z); t[3] += (a.w + b.w) + (c.w + d.w);
+            }
             if (vst) {
                 float4* o = (float4*)(dw + (int64_t)co * ld + ci);
                 float4 v = make_float4(t[0], t[1], t[2], t[3]);
@@ -410,20 +441,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
 static void launch_wgrad_reduce(hipStream_t st, const float* partials, float* dw, int cin, int cout, int nslots, int nchunks, int ncg, int cgw, int accumulate,
                                 int taps, const float* db_partials, float* db, int ld) {
     const int64_t total = (int64_t)cout * taps * cin;
-    const int nb_db = db ? (cout + 255) / 256 : 0;
+    const int nb_db = db ? (cout + 63) / 64 : 0;            // a bias block owns 64 columns
     // same-box A/B (bench.py, MI355X): token GEMMs (taps 1, float4 stores) +1.1 % on SwinIR-M's step; 3x3 weights (stride-9 stores either way) within
     // noise on MoSR / SPAN and -0.5 % on ESRGAN's L1-only step, so only the ksize-1 reductions take the 16-byte form
+    // few outputs, many slots (SPAN's 52 / 104 / 156-channel 1x1 and 3x3 weights: a few thousand outputs x 96-384 slots): 16 waves per block share an
+    // output's slots, so the walk is 6 dependent steps instead of 24 and the launch has four times the waves; the bias columns' slots are shared by a block's waves the same way
+    // (one thread per column walked all 384 slots alone: that, not the weight part, was SPAN's 31 us per launch)
+    const bool wide = nslots >= 64 && total < (int64_t)64 * 2048;
     if (tr::tune().wgrad_reduce == 0 && taps == 1 && cin % 4 == 0 && ((uintptr_t)partials % 16) == 0) {
         int64_t b = (total / 4 + 63) / 64;
         if (b > 8192) b = 8192;
         const int vst = taps == 1 && ld % 4 == 0 && ((uintptr_t)dw % 16) == 0;
-        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate,
-                           taps, (int)b, db_partials, db, ld, vst);
+        const int nbb = nb_db;
+        if (wide) hipLaunchKernelGGL(wgrad_reduce_vec_kernel<16>, dim3((unsigned)(b + nbb)), dim3(1024), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate,
+                                     taps, (int)b, db_partials, db, ld, vst);
+        else hipLaunchKernelGGL(wgrad_reduce_vec_kernel<4>, dim3((unsigned)(b + nbb)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate,
+                                taps, (int)b, db_partials, db, ld, vst);
         return;
     }
     int64_t b = (total + 63) / 64;
     if (b > 8192) b = 8192;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps,
+    if (wide) {
+        const int nbb = nb_db;
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(b + nbb)), dim3(1024), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps,
+                           (int)b, db_partials, db, ld);
+        return;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(b + nb_db)), dim3(256), 0, st, partials, dw, cin, cout, nslots, nchunks, ncg, cgw, accumulate, taps,
                        (int)b, db_partials, db, ld);
 }
 
@@ -782,7 +826,7 @@ extern "C" int tr_wgrad3x3_multi(void* stream, const tr_wgrad3x3_desc* descs, in
             ReduceOne& q = m.r[k];
             q.partials = d.partials; q.dw = d.dw; q.db_partials = d.partials + dw_floats; q.db = d.db;
             q.cin = d.cin; q.cout = d.cout; q.nslots = nslots; q.nchunks = nchunks; q.ncg = ncg; q.cgw = 32; q.accumulate = d.accumulate; q.taps = 9;
-            q.nb_dw = (int)b; q.nb_db = d.db ? (d.cout + 255) / 256 : 0; q.ld = d.dw_ld > 0 ? d.dw_ld : d.cin;
+            q.nb_dw = (int)b; q.nb_db = d.db ? (d.cout + 63) / 64 : 0; q.ld = d.dw_ld > 0 ? d.dw_ld : d.cin;
             if ((unsigned)(q.nb_dw + q.nb_db) > gx) gx = (unsigned)(q.nb_dw + q.nb_db);
         }
         hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(gx, (unsigned)ndesc), dim3(256), 0, (hipStream_t)stream, m);
