@@ -114,7 +114,7 @@ class ConvTimer:
         timer = self
 
         def timed(**kw):
-            if not timer.enabled:
+            if not timer.enabled or torch.cuda.is_current_stream_capturing():      # a launch recorded into a hipGraph cannot carry timing events
                 return orig(**kw)
             cd = "bf16" if kw["compute"] == L.BF16 else "f16" if kw["compute"] == L.F16 else "f32w" if kw["compute"] == L.F32_WINOGRAD else "f32w4" if kw["compute"] == L.F32_WINOGRAD43 else "f32"
             ks = kw.get("ksize", 3)
@@ -360,20 +360,24 @@ def roofline(args, agg, dt, n, s, warm=None):
         return tkey, e
 
     table = {}
+    replayed = not agg            # the timed region replayed hipGraphs: no launch went through the timer, the eager warm-up step is all there is
     for k, v in (warm or {}).items():
         if k not in agg:
             tk, e0 = entry(k, v)
-            e0["measured_in"] = "last warm-up step (1 step)"
+            e0["measured_in"] = "eager warm-up step (1 step); the timed region replays the step as hipGraphs" if replayed else "last warm-up step (1 step)"
             table[tk] = e0
     for k, v in agg.items():
         tk, e0 = entry(k, v)
         e0["measured_in"] = "timed region"
         table[tk] = e0
+    nsteps_agg = 1 if replayed else None
+    if replayed:
+        agg = warm
     key = max(agg, key=lambda k: agg[k][2])
     tkey, e = entry(key, agg[key])
     names = {"f32w": "winograd_f32_kernel (fused Winograd F(2x2,3x3), fp32 MFMA)", "f32w4": "winograd43_f32_kernel (fused Winograd F(4x4,3x3), fp32 MFMA)"}
     fam = max(e["kernel_family"], key=e["kernel_family"].get)
-    fam_name = {"ring": "conv_ring_kernel (persistent LDS-DMA ring)", "reg": "conv3x3_kernel_reg (register-staged)", "linear": "linear_kernel (token GEMM)",
+    fam_name = {"ring": "conv_ring_kernel (persistent LDS-DMA ring)", "reg": "conv3x3_kernel_reg (register-staged)", "linear": "linear_kernel (token GEMM)", "linear_dma": "linear_dma_kernel (LDS-DMA staged token GEMM)",
                 "dma": "conv3x3_kernel_dma"}.get(fam, fam)
     kname = names.get(key[0], f"{fam_name} <{key[0]}, cout-group {key[1]}, ksize {key[2]}>")
     mfma = e["bound"] == "mfma"
@@ -382,13 +386,15 @@ def roofline(args, agg, dt, n, s, warm=None):
          "unit": "TFLOP/s" if mfma else "GB/s", "frac": e["mfma_frac"] if mfma else e["algorithmic_hbm_frac"],
          "traffic": e.get("traffic"), "hbm_frac": e.get("hbm_frac"), "algorithmic_bytes_per_launch": e["algorithmic_bytes_per_launch"],
          "traffic_over_algorithmic": e.get("traffic_over_algorithmic"),
-         "flop_per_launch": agg[key][1] / agg[key][0], "launches": agg[key][0], "avg_launch_ms": e["avg_launch_ms"], "share_of_step": agg[key][2] / (dt * 1e3),
+         "flop_per_launch": agg[key][1] / agg[key][0], "launches": agg[key][0], "avg_launch_ms": e["avg_launch_ms"], "share_of_step": agg[key][2] / (nsteps_agg or args.steps) / (dt * 1e3),
          "algorithmic_tflops": e["algorithmic_tflops"], "algorithmic_vs_direct_peak": e["algorithmic_tflops"] / PEAK_TFLOPS[key[0]],
          "note": ("achieved / frac = FLOPs the kernel EXECUTES on the MFMA pipe (algorithmic 3x3-conv FLOPs / "
                   f"{WINO_FACTOR.get(key[0], 1.0):g}) over the launch time, against the dense {key[0][:3]} MFMA peak; algorithmic_* = the 2*9*Cin*Cout-per-pixel "
                   "rate of the convolution itself (DESIGN.md section 4)") if mfma else
                  "achieved / frac = algorithmic bytes (input once + every output / side view once) over the launch time, against 8 TB/s",
          "all": table}
+    if replayed:
+        r["measured_in"] = "eager warm-up step: the timed region replays the step as hipGraphs, where a launch cannot carry HIP events"
     if r["traffic"] is not None:
         # the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md) count every L2 miss, Infinity-Cache hits included
         r["traffic_note"] = ("traffic = L2-miss bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes; Infinity-Cache hits are counted.  "
@@ -501,13 +507,17 @@ def main():
     warm_records = None
     for k in range(args.warmup):
         it += 1
-        if k == args.warmup - 1 and not args.no_roofline:
+        if (k >= 1 or args.warmup == 1) and not args.no_roofline:
+            # every warm-up step after the first is timed; the latest one that recorded launches counts.  A generator that replays its step as
+            # hipGraphs (SwinIR) launches nothing through the Python wrapper once captured: its last EAGER warm-up step supplies the table.
             fence()
             timer.enabled = True
             step(it)
             fence()
             timer.enabled = False
-            warm_records, timer.records = timer.records, []
+            if timer.records:
+                warm_records = timer.records
+            timer.records = []
         else:
             step(it)
     fence()
@@ -542,8 +552,8 @@ def main():
                        "global_batch": n * world, "lq_size": s, "parallelism": f"dp{world}", "losses": args.losses,
                        "l_g_total": stats.get("l_g_total")},
         }
-        if not args.no_roofline and timer.records:
-            out["roofline"] = roofline(args, timer.summary(), dt, n, s, timer.summary(warm_records) if warm_records else None)
+        if not args.no_roofline and (timer.records or warm_records):
+            out["roofline"] = roofline(args, timer.summary(), dt / args.steps, n, s, timer.summary(warm_records) if warm_records else None)
         if world == 1 and not args.fast_matmul and "perceptual" in args.losses and not args.no_variants:
             # informational second measurement (NOT `value`): the reference's `fast_matmul: true` option, which on gfx950 (no TF32) is the
             # split-bf16 path of the fp32-forced VGG head (3 bf16 MFMAs per product; measured 3e-6 rel-L2 per conv vs exact fp32)

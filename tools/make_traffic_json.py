@@ -12,7 +12,7 @@ groups = {}
 for k in fe:
     m = re.search(r"conv3x3_kernel_reg<(\d), (\d), (\d), (\d)>", k)
     mr = re.search(r"conv_ring_kernel<(\d), (\d),", k)
-    ml = re.search(r"linear_kernel<(\d), (\d)>", k)
+    ml = re.search(r"linear(?:_dma)?_kernel<(\d), (\d)", k)      # token GEMM, register-staged or LDS-DMA staged: one group
     name = lambda ct: "f32" if ct == 0 else "bf16" if ct == 1 else "f16"  # noqa: E731
     if "winograd43_f32_kernel" in k:
         key = "f32/winograd43"
